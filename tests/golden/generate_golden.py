@@ -1,0 +1,201 @@
+"""Generate golden vectors by running the REAL reference in the build container.
+
+Run once, here (needs /root/reference; the GPU box has neither the reference nor a need for
+this script):
+
+    python tests/golden/generate_golden.py
+
+It imports, unmodified and from where they lie, the reference's
+    modules/matchingpursuit.py  modules/conv.py  modules/normalization.py  modules/sparse.py
+    modules/stft.py
+behind two stub packages (`modules` as a bare namespace so that modules/__init__.py -- which
+drags in librosa/zounds -- is not executed, and `util` providing only `device`).
+`iterative_loss` / `sort_channels_descending_norm` live in modules/iterative.py, whose
+module-level imports need the whole package; those two pure-torch functions are taken from
+its AST and executed on their own.
+
+Nothing from the reference is copied into this repository: the outputs are data only
+(inputs, selected (atom, lag, gain) sequences, residuals, dictionaries, losses), written as
+.npz files beside this script.  Every encode fixture also stores, per step, the top-2 values
+of the reference's own feature map, so that a test can tell a real disagreement from a
+near-tie that no fp32 summation order is obliged to reproduce.
+"""
+import ast
+import importlib
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(os.path.dirname(HERE))
+REF = "/root/reference"
+sys.path.insert(0, os.path.join(REPO, "matching-pursuit_amd"))
+from mpcore import synth  # noqa: E402
+
+
+def load_reference():
+    m = types.ModuleType("modules")
+    m.__path__ = [os.path.join(REF, "modules")]
+    sys.modules["modules"] = m
+    u = types.ModuleType("util")
+    u.device = torch.device("cpu")
+    sys.modules["util"] = u
+    mp = importlib.import_module("modules.matchingpursuit")
+    conv = importlib.import_module("modules.conv")
+    norm = importlib.import_module("modules.normalization")
+    stft = importlib.import_module("modules.stft")
+    # iterative_loss + sort_channels_descending_norm: pure functions out of iterative.py's AST
+    src = open(os.path.join(REF, "modules", "iterative.py")).read()
+    tree = ast.parse(src)
+    keep = [n for n in tree.body if isinstance(n, ast.FunctionDef)
+            and n.name in ("iterative_loss", "sort_channels_descending_norm")]
+    ns = {"torch": torch, "TensorTransform": object}
+    exec(compile(ast.Module(body=keep, type_ignores=[]), "iterative.py<extract>", "exec"), ns)
+    return mp, conv, norm, stft, ns
+
+
+def run_encode(mp, signal, d, n_steps, approx=None):
+    """Reference sparse_code in SELECTION order via the visit_key_point hook (:323-324)."""
+    B, _, N = signal.shape
+    rec = {"atom": [], "lag": [], "gain": [], "top2": []}
+
+    def visit(fm, ai, p, a):
+        flat = fm.reshape(-1)
+        top = torch.topk(flat, 2).values
+        rec["atom"].append(int(ai))
+        rec["lag"].append(int(p))
+        rec["gain"].append(float(fm[ai, int(p)]))
+        rec["top2"].append(top.numpy().copy())
+
+    with torch.no_grad():
+        events, scatter, residual = mp.sparse_code(
+            signal, d, n_steps=n_steps, flatten=True, return_residual=True,
+            visit_key_point=visit, approx=approx)
+    K = n_steps
+    # the hook fires step-major, batch-minor -> reshape to [B, K]
+    atom = np.array(rec["atom"], dtype=np.int64).reshape(K, B).T.copy()
+    lag = np.array(rec["lag"], dtype=np.int64).reshape(K, B).T.copy()
+    gain = np.array(rec["gain"], dtype=np.float32).reshape(K, B).T.copy()
+    top2 = np.array(rec["top2"], dtype=np.float32).reshape(K, B, 2).transpose(1, 0, 2).copy()
+    # grouped-by-atom order of flatten=True (:61-65), as (atom, batch, lag) triples
+    flat_order = np.array([[e[0], e[1], int(e[2])] for e in events], dtype=np.int64)
+    recon = scatter(signal.shape, events).detach().numpy()[:, 0, :]
+    return dict(atom=atom, lag=lag, gain=gain, top2=top2, flat_order=flat_order,
+                residual=residual.numpy()[:, 0, :].copy(), recon=recon.astype(np.float32))
+
+
+ENCODE_CASES = [
+    # name, A, L, N, B, K, n_events, seed
+    ("c1_16x256_n8192_b1_k8", 16, 256, 8192, 1, 8, 6, 101),       # BASELINE configs[0]
+    ("mid_64x128_n4096_b3_k16", 64, 128, 4096, 3, 16, 12, 202),
+    ("ragged_24x100_n1000_b2_k12", 24, 100, 1000, 2, 12, 8, 303),  # nothing a power of two
+    ("c2shape_512x512_n32768_b2_k12", 512, 512, 32768, 2, 12, 36, 404),  # configs[1] shape
+]
+
+
+def main():
+    torch.manual_seed(0)
+    torch.set_num_threads(8)
+    mp, conv, norm, stft_mod, itns = load_reference()
+    report = []
+
+    for name, A, L, N, B, K, n_ev, seed in ENCODE_CASES:
+        d = synth.make_dictionary(A, L, seed=seed)
+        x = synth.make_segments(B, N, d, n_events=n_ev, seed=seed)
+        sig = torch.from_numpy(x)[:, None, :]
+        dt = torch.from_numpy(d)
+        out = run_encode(mp, sig, dt, K)
+        out_fft = run_encode(mp, sig, dt, K, approx=N + 1)  # exact FFT branch, conv.py:48-49
+        d_unit = norm.unit_norm(dt).numpy()
+        gap = (out["top2"][..., 0] - out["top2"][..., 1]) / np.abs(out["top2"][..., 0])
+        rdb = 20 * np.log10(np.linalg.norm(out["residual"], axis=-1) / np.linalg.norm(x, axis=-1))
+        small = dict(signal=x, d_unit=d_unit.astype(np.float32),
+                     atom=out["atom"], lag=out["lag"], gain=out["gain"], top2=out["top2"],
+                     flat_order=out["flat_order"], residual=out["residual"], recon=out["recon"],
+                     residual_db=rdb.astype(np.float64),
+                     fft_atom=out_fft["atom"], fft_lag=out_fft["lag"], fft_gain=out_fft["gain"],
+                     fft_residual=out_fft["residual"], seed=np.int64(seed))
+        # the raw dictionary is reproducible from synth.make_dictionary(A, L, seed); store it
+        # only for the small cases, and always store the reference's unit-normed copy
+        if A * L <= 16384:
+            small["d_raw"] = d
+        np.savez_compressed(os.path.join(HERE, f"encode_{name}.npz"), **small)
+        report.append((name, float(gap.min()), rdb.tolist(),
+                       bool((out["atom"] == out_fft["atom"]).all() and (out["lag"] == out_fft["lag"]).all())))
+
+    # dictionary_learning_step (:348-419)
+    for name, A, L, N, B, K, n_ev, seed in [("dl_32x64_n2048_b4_k10", 32, 64, 2048, 4, 10, 10, 505),
+                                            ("dl_16x256_n8192_b2_k8", 16, 256, 8192, 2, 8, 6, 606)]:
+        d = synth.make_dictionary(A, L, seed=seed)
+        x = synth.make_segments(B, N, d, n_events=n_ev, seed=seed)
+        with torch.no_grad():
+            d_in = torch.from_numpy(d.copy())
+            d_new = mp.dictionary_learning_step(torch.from_numpy(x)[:, None, :], d_in, n_steps=K)
+            assert np.array_equal(d_in.numpy(), d), "reference mutated its input dictionary"
+            enc = run_encode(mp, torch.from_numpy(x)[:, None, :], torch.from_numpy(d), K)
+        gap = (enc["top2"][..., 0] - enc["top2"][..., 1]) / np.abs(enc["top2"][..., 0])
+        np.savez_compressed(os.path.join(HERE, f"{name}.npz"), signal=x, d_raw=d,
+                            d_new=d_new.numpy().astype(np.float32), n_steps=np.int64(K),
+                            atom=enc["atom"], lag=enc["lag"], top2=enc["top2"])
+        report.append((name, float(gap.min()), None, None))
+
+    # primitives: unit_norm, torch_conv vs fft_convolve (conv.py:4-53), scatter_segments decode
+    rng = np.random.Generator(np.random.PCG64(707))
+    d = rng.uniform(-1, 1, (8, 32)).astype(np.float32)
+    sig = rng.standard_normal((2, 1, 300)).astype(np.float32)
+    du = norm.unit_norm(torch.from_numpy(d))
+    fm_direct = conv.torch_conv(torch.from_numpy(sig), du).numpy()
+    fm_fft = conv.fft_convolve(torch.from_numpy(sig), du).numpy()
+    scatter = mp.build_scatter_segments(300, 32)
+    ev_atom = np.array([3, 3, 7, 0, 5], dtype=np.int64)
+    ev_batch = np.array([0, 1, 0, 1, 1], dtype=np.int64)
+    ev_lag = np.array([0, 290, 120, 131, 268], dtype=np.int64)   # two events cropped at N
+    ev_gain = np.array([1.5, -0.75, 2.0, 0.3, 1.1], dtype=np.float32)
+    inst = [(int(a), int(b), torch.tensor([[int(p)]]), (du[int(a)] * float(g)).view(1, 1, 32))
+            for a, b, p, g in zip(ev_atom, ev_batch, ev_lag, ev_gain)]
+    dec = scatter((2, 1, 300), inst).detach().numpy()
+    np.savez_compressed(os.path.join(HERE, "primitives.npz"), d_raw=d, d_unit=du.numpy(), signal=sig,
+                        fm_direct=fm_direct, fm_fft=fm_fft, ev_atom=ev_atom, ev_batch=ev_batch,
+                        ev_lag=ev_lag, ev_gain=ev_gain, decoded=dec)
+
+    # sparse_feature_map (:68-125): nonzero coordinates + values + residual
+    d = synth.make_dictionary(16, 64, seed=808)
+    x = synth.make_segments(2, 1024, d, n_events=6, seed=808)
+    with torch.no_grad():
+        fm, res = mp.sparse_feature_map(torch.from_numpy(x), torch.from_numpy(d), n_steps=6,
+                                        return_residual=True)
+    nz = torch.nonzero(fm)
+    np.savez_compressed(os.path.join(HERE, "sparse_feature_map.npz"), signal=x, d_raw=d,
+                        nz_index=nz.numpy(), nz_value=fm[nz[:, 0], nz[:, 1], nz[:, 2]].numpy(),
+                        residual=res.numpy()[:, 0, :], n_steps=np.int64(6))
+
+    # iterative_loss (modules/iterative.py:24-74) with the stft transform
+    # (iterativedecomposition.py:81-86 uses stft(x, 2048, 256, pad=True))
+    rng = np.random.Generator(np.random.PCG64(909))
+    target = rng.standard_normal((2, 1, 4096)).astype(np.float32)
+    chans = (rng.standard_normal((2, 5, 4096)) * rng.uniform(0.05, 1.0, (2, 5, 1))).astype(np.float32)
+
+    def transform(t):
+        return stft_mod.stft(t, 512, 128, pad=True)
+
+    outs = {}
+    for tag, kw in [("default", {}), ("ratio", {"ratio_loss": True}), ("nosort", {"sort_channels": False})]:
+        r, l = itns["iterative_loss"](torch.from_numpy(target), torch.from_numpy(chans), transform,
+                                      return_residual=True, **kw)
+        outs[f"residual_{tag}"] = r.numpy()
+        outs[f"loss_{tag}"] = np.float64(l.item())
+    srt = itns["sort_channels_descending_norm"](torch.from_numpy(chans)).numpy()
+    tr = transform(torch.from_numpy(target)).numpy()
+    np.savez_compressed(os.path.join(HERE, "iterative_loss.npz"), target=target, channels=chans,
+                        sorted_channels=srt, stft_target=tr, **outs)
+
+    print("fixture report (name, min relative top-2 gap, residual dB, direct==fft picks):")
+    for r in report:
+        print("  ", r)
+
+
+if __name__ == "__main__":
+    main()

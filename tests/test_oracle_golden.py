@@ -1,0 +1,88 @@
+"""The oracle (oracle/mp_oracle.c) against golden vectors produced by the real reference
+(tests/golden/generate_golden.py).  This is what pins the oracle; the GPU parity tests then
+hold the HIP path to the oracle bit for bit."""
+import glob
+import os
+
+import numpy as np
+import pytest
+
+from mpcore import synth
+
+REL = 1e-5  # BASELINE.json north_star: gains and residual within 1e-5 relative fp32
+
+
+def _raw_dict(z):
+    if "d_raw" in z.files:
+        return z["d_raw"]
+    A, L = z["d_unit"].shape
+    return synth.make_dictionary(A, L, seed=int(z["seed"]))
+
+
+def _encode_cases(golden_dir):
+    return sorted(glob.glob(os.path.join(golden_dir, "encode_*.npz")))
+
+
+def test_fixtures_present(golden_dir):
+    assert len(_encode_cases(golden_dir)) >= 4
+
+
+@pytest.mark.parametrize("name", ["encode_c1_16x256_n8192_b1_k8", "encode_mid_64x128_n4096_b3_k16",
+                                  "encode_ragged_24x100_n1000_b2_k12",
+                                  "encode_c2shape_512x512_n32768_b2_k12"])
+def test_oracle_encode_matches_reference(oracle, golden_dir, name):
+    z = np.load(os.path.join(golden_dir, name + ".npz"))
+    d_raw = _raw_dict(z)
+    du = oracle.unit_norm(d_raw)
+    # unit_norm (normalization.py:4-6) agrees with the reference's copy
+    assert np.abs(du - z["d_unit"]).max() <= 2e-7
+    K = z["atom"].shape[1]
+    out = oracle.encode(z["signal"], du, K)
+    gap = (z["top2"][..., 0] - z["top2"][..., 1]) / np.abs(z["top2"][..., 0])
+    assert gap.min() >= 1e-4, "fixture has a near-tie; regenerate with another seed"
+    assert np.array_equal(out["atom"], z["atom"])
+    assert np.array_equal(out["lag"], z["lag"])
+    assert np.abs(out["gain"] - z["gain"]).max() <= REL * np.abs(z["gain"]).max()
+    assert np.abs(out["residual"] - z["residual"]).max() <= REL * np.abs(z["signal"]).max()
+    rdb = 20 * np.log10(np.linalg.norm(out["residual"], axis=-1) / np.linalg.norm(z["signal"], axis=-1))
+    assert np.abs(rdb - z["residual_db"]).max() <= 1e-3
+    # the reference's FFT branch picked the same events (conv.py:11-53)
+    assert np.array_equal(out["atom"], z["fft_atom"]) and np.array_equal(out["lag"], z["fft_lag"])
+    # decode: scatter of the events reproduces signal - residual
+    B, N = z["signal"].shape
+    batch = np.repeat(np.arange(B), K)
+    rec = oracle.scatter(out["atom"].ravel(), batch, out["lag"].ravel(), out["gain"].ravel(), du, B, N)
+    assert np.abs(rec - z["recon"]).max() <= REL * max(1.0, np.abs(z["recon"]).max())
+
+
+def test_oracle_feature_map_and_decode_primitives(oracle, golden_dir):
+    z = np.load(os.path.join(golden_dir, "primitives.npz"))
+    du = oracle.unit_norm(z["d_raw"])
+    assert np.abs(du - z["d_unit"]).max() <= 2e-7
+    fm = oracle.feature_map(z["signal"][:, 0, :], du)
+    scale = np.abs(z["fm_direct"]).max()
+    assert np.abs(fm - z["fm_direct"]).max() <= REL * scale
+    assert np.abs(fm - z["fm_fft"]).max() <= REL * scale
+    arb = oracle.arbiter_feature_map(z["signal"][:, 0, :], du)
+    assert np.abs(fm - arb).max() <= REL * scale
+    dec = oracle.scatter(z["ev_atom"], z["ev_batch"], z["ev_lag"], z["ev_gain"], du, 2, 300)
+    assert np.abs(dec - z["decoded"][:, 0, :]).max() <= 1e-6
+
+
+@pytest.mark.parametrize("name", ["dl_32x64_n2048_b4_k10", "dl_16x256_n8192_b2_k8"])
+def test_oracle_dictionary_learning_step(oracle, golden_dir, name):
+    z = np.load(os.path.join(golden_dir, name + ".npz"))
+    d_new = oracle.dictionary_learning_step(z["signal"], z["d_raw"], int(z["n_steps"]))
+    # atoms are unit norm, so an absolute bound is a relative one
+    assert np.abs(d_new - z["d_new"]).max() <= 1e-5
+
+
+def test_oracle_is_deterministic_across_thread_counts(oracle):
+    d = oracle.unit_norm(synth.make_dictionary(24, 100, seed=1))
+    x = synth.make_segments(2, 1000, d, n_events=8, seed=1)
+    oracle.set_num_threads(1)
+    a = oracle.encode(x, d, 10)
+    oracle.set_num_threads(4)
+    b = oracle.encode(x, d, 10)
+    for k in ("atom", "lag", "gain", "residual"):
+        assert np.array_equal(a[k], b[k])
