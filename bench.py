@@ -1,0 +1,203 @@
+#!/usr/bin/env python3
+"""Benchmark of the matching-pursuit hot path on MI355X (contract: see DESIGN.md "Measurement").
+
+    python bench.py --gpus N --steps K --warmup W
+
+Workload = BASELINE.json configs[1] per GPU: 512-atom x 512-sample dictionary, 64 segments of
+32768 samples, 64 MP iterations per segment.  One "step" = one mp_encode_f32 call over the
+batch = 64 x 64 = 4096 segment-iterations.  With N > 1 (launched by torch.distributed.run, one
+rank per GPU) every rank encodes its own 64 segments (configs[2] at N = 8: 512 segments), no
+collective on the data path, weak scaling; rank 0 prints ONE JSON line.
+
+value = segment-iterations/s over all ranks, inputs resident in HBM, timed between
+barrier+synchronize pairs, max over ranks.  `roofline` is for the dominant kernel (the MFMA
+correlate kernel) from HIP events recorded inside the timed region on the launch stream;
+`cpu_baseline` is the CPU oracle timed on this host (rank 0, N = 1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(REPO, "matching-pursuit_amd"))
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+from mpcore import _native as nat  # noqa: E402
+from mpcore import dist as mpdist  # noqa: E402
+from mpcore import synth  # noqa: E402
+
+A, L, N, B_PER_GPU, K_ITERS = 512, 512, 32768, 64, 64
+PEAK_MFMA_F32_TFLOPS = 157.3  # MI355X dense fp32 matrix peak (MI355X_MICROARCH.md)
+
+
+def algorithmic_flops(lag, path):
+    """Algorithmic flop of ONE encode of this rank's batch for the correlate kernel.
+    full pass: 2*A*L*N per segment (17.18 GFLOP at this shape);
+    incremental launch k>=1: 2*A*L*(lags whose window the previous event touched)."""
+    Bn, K = lag.shape
+    full = 2.0 * A * L * N * Bn
+    if path == nat.MP_PATH_DIRECT:
+        return full * K, full * K, 0.0
+    p = lag[:, : K - 1].astype(np.int64)
+    lo = np.maximum(p - L + 1, 0)
+    hi = np.minimum(p + L - 1, N - 1)
+    inc = float((2.0 * A * L * (hi - lo + 1)).sum())
+    return full + inc, full, inc
+
+
+def timed_encodes(x, du, steps, warmup, path, flags, group):
+    for _ in range(warmup):
+        out = nat.encode(x, du, K_ITERS, path=path, flags=flags, want_residual=True)
+    torch.cuda.synchronize()
+    nat.profile_read()  # drop warm-up spans
+    mpdist.barrier(group)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        out = nat.encode(x, du, K_ITERS, path=path, flags=flags, want_residual=True)
+    torch.cuda.synchronize()
+    mpdist.barrier(group)
+    dt = time.perf_counter() - t0
+    t = torch.tensor([dt], dtype=torch.float64, device=x.device)
+    t = mpdist.all_reduce_max(t, group)
+    return float(t.item()), out, nat.profile_read()
+
+
+def roofline_from(prof, flops_one_encode, steps):
+    ms_full, n_full = prof["corr_full"]
+    ms_inc, n_inc = prof["corr_inc"]
+    total, _, _ = flops_one_encode
+    launches = n_full + n_inc
+    if launches == 0:
+        return None
+    sec = (ms_full + ms_inc) * 1e-3
+    achieved = total * steps / sec / 1e12
+    return {
+        "bound": "mfma", "achieved": round(achieved, 3), "peak": PEAK_MFMA_F32_TFLOPS, "unit": "TFLOP/s",
+        "frac": round(achieved / PEAK_MFMA_F32_TFLOPS, 4), "traffic": None,
+        "kernel": "correlate_mfma_kernel (v_mfma_f32_32x32x2_f32)",
+        "launches": launches, "avg_launch_ms": round((ms_full + ms_inc) / launches, 5),
+        "full_pass_launches": n_full, "full_pass_avg_ms": round(ms_full / max(n_full, 1), 5),
+        "incremental_launches": n_inc, "incremental_avg_ms": round(ms_inc / max(n_inc, 1), 5),
+        "select_avg_ms": round(prof["select"][0] / max(prof["select"][1], 1), 5),
+        "algorithmic_gflop_per_launch": round(total * steps / launches / 1e9, 3),
+    }
+
+
+def cpu_baseline(d, x_host, gpu_sample):
+    """The oracle (oracle/mp_oracle.c, the CPU restatement of the reference) on this host's cores,
+    on a bounded sample of the same workload; also the in-run parity check."""
+    sys.path.insert(0, os.path.join(REPO, "oracle"))
+    import mp_oracle
+    mp_oracle.build()
+    threads = mp_oracle.num_threads()
+    du = mp_oracle.unit_norm(d)
+    t0 = time.perf_counter()
+    mp_oracle.encode(x_host[:1], du, 2)
+    per = (time.perf_counter() - t0) / 2
+    k_s = 8
+    b_s = int(min(max(round(15.0 / (per * k_s)), 1), 16, x_host.shape[0]))
+    t0 = time.perf_counter()
+    want = mp_oracle.encode(x_host[:b_s], du, k_s)
+    dt = time.perf_counter() - t0
+    atom, lag, gain = gpu_sample
+    parity = {
+        "segments": b_s, "steps": k_s,
+        "indices_equal": bool(np.array_equal(atom[:b_s, :k_s], want["atom"]) and
+                              np.array_equal(lag[:b_s, :k_s], want["lag"])),
+        "gain_max_rel_err": float(np.abs(gain[:b_s, :k_s] - want["gain"]).max() / np.abs(want["gain"]).max()),
+    }
+    return {
+        "value": round(b_s * k_s / dt, 3), "unit": "segment-iterations/s", "cores": threads, "kind": "port",
+        "sample": f"{b_s} of the 64 segments x {k_s} iterations (rate is K-independent), "
+                  f"oracle/mp_oracle.c with OpenMP on {threads} threads, {dt:.1f} s",
+    }, parity
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--path", default="incremental", choices=["incremental", "direct"])
+    ap.add_argument("--flags", type=int, default=0)
+    ap.add_argument("--no-variants", action="store_true", help="skip the direct-path variant leg")
+    ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
+    args = ap.parse_args()
+
+    rank, world, local_rank = mpdist.init_from_env()
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run "
+                         f"--nproc-per-node {args.gpus}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
+    dev = torch.device("cuda", local_rank if world > 1 else 0)
+    torch.cuda.set_device(dev)
+    group = None
+
+    d = synth.make_dictionary(A, L, seed=1000)
+    x_host = synth.make_segments(B_PER_GPU, N, d, n_events=3 * K_ITERS, seed=1002,
+                                 first_index=rank * B_PER_GPU)
+    x = torch.from_numpy(x_host).to(dev)
+    du = nat.unit_norm(torch.from_numpy(d).to(dev))
+    torch.cuda.synchronize()
+
+    nat.profile_enable(True)
+    path = nat.MP_PATH_INCREMENTAL if args.path == "incremental" else nat.MP_PATH_DIRECT
+    dt, out, prof = timed_encodes(x, du, args.steps, args.warmup, path, args.flags, group)
+    atom, lag, gain, residual = [t.cpu().numpy() for t in out]
+    seg_its = world * B_PER_GPU * K_ITERS * args.steps
+    flops = algorithmic_flops(lag, path)
+    roof = roofline_from(prof, flops, args.steps)
+    rdb = 20 * np.log10(np.linalg.norm(residual, axis=-1) / np.linalg.norm(x_host, axis=-1))
+
+    line = {
+        "metric": "MP iterations/sec (32768-samp seg, 512x512 dict, K=64)",
+        "value": round(seg_its / dt, 2), "unit": "segment-iterations/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(dt / args.steps * 1e3, 4),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic",
+        "config": {
+            "workload": "BASELINE configs[1] per GPU: 512x512 dictionary, 64 x 32768-sample segments, K=64"
+                        + (f" (x{world} ranks = configs[2])" if world > 1 else ""),
+            "path": args.path, "global_batch": world * B_PER_GPU, "n_samples": N, "n_atoms": A,
+            "atom_samples": L, "iterations": K_ITERS, "segment_iterations_per_step": world * B_PER_GPU * K_ITERS,
+            "parallelism": f"segments sharded over {world} rank(s), no data-path collective",
+        },
+        "roofline": roof,
+        "residual_db_mean": round(float(rdb.mean()), 4),
+    }
+
+    if rank == 0 and world == 1:
+        if not args.no_variants:
+            other = nat.MP_PATH_DIRECT if path == nat.MP_PATH_INCREMENTAL else nat.MP_PATH_INCREMENTAL
+            name = "direct_full_recompute" if other == nat.MP_PATH_DIRECT else "incremental"
+            vsteps = max(1, min(args.steps, 2))
+            vdt, vout, vprof = timed_encodes(x, du, vsteps, 1, other, args.flags, group)
+            vlag = vout[1].cpu().numpy()
+            same = all(torch.equal(p, q) for p, q in zip(vout, out))
+            line["variants"] = {name: {
+                "value": round(B_PER_GPU * K_ITERS * vsteps / vdt, 2), "unit": "segment-iterations/s",
+                "ms_per_step": round(vdt / vsteps * 1e3, 4), "steps": vsteps,
+                "bit_identical_to_headline": bool(same),
+                "roofline": roofline_from(vprof, algorithmic_flops(vlag, other), vsteps),
+            }}
+        if not args.no_cpu:
+            base, parity = cpu_baseline(d, x_host, (atom, lag, gain))
+            line["cpu_baseline"] = base
+            line["parity_vs_cpu_oracle"] = parity
+            line["speedup_vs_cpu_baseline"] = round(line["value"] / base["value"], 1)
+    nat.profile_enable(False)
+    if rank == 0:
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,132 @@
+/*
+ * mpcore.h -- C ABI of libmpcore.so, the MI355X (gfx950) greedy matching-pursuit encoder.
+ *
+ * The reference (JohnVinyard/matching-pursuit) has no FFI: its boundary for this path is a
+ * set of Python functions over torch tensors.  Each entry point below replaces the torch
+ * ops one of those functions spends its time in; the citation says which (paths relative
+ * to the reference checkout).  The Python mirror of the reference surface that calls these
+ * through ctypes is matching-pursuit_amd/mpcore/ (see INTEGRATION.md for the binding).
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer to caller-owned, contiguous memory unless stated;
+ *     nothing is allocated or freed on the caller's behalf (workspace is caller-supplied,
+ *     so PyTorch's caching allocator owns all memory);
+ *   - every call is asynchronous on `stream` (a hipStream_t passed as void*; NULL = the
+ *     null stream) and may be captured into a hipGraph: no host synchronisation inside;
+ *   - return value: 0 = ok, negative = error; mp_last_error() (thread-local) says why;
+ *   - all floating data is fp32; indices are int64 at the boundary (torch's index type);
+ *   - C == 1 (mono) only.
+ */
+#ifndef MPCORE_H
+#define MPCORE_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MP_OK 0
+#define MP_ERR_ARG (-1)       /* bad shape / null pointer / unsupported size            */
+#define MP_ERR_WORKSPACE (-2) /* workspace too small or misaligned                      */
+#define MP_ERR_HIP (-3)       /* a HIP runtime call failed (message has hipGetErrorString) */
+#define MP_ERR_UNSUPPORTED (-4)
+
+/* How the per-iteration correlation is scheduled.  All paths select bit-identical events. */
+#define MP_PATH_DIRECT 0      /* full A x N correlation every iteration (what the reference
+                                 recomputes each step, modules/matchingpursuit.py:275-277)  */
+#define MP_PATH_FFT 1         /* reserved: FFT correlation (modules/conv.py:11-53)          */
+#define MP_PATH_INCREMENTAL 2 /* full correlation once, then only the lags an event touched
+                                 ([p-L+1, p+L-1]); untouched block maxima are reused        */
+#define MP_PATH_NAIVE 8       /* one-thread-per-lag fmaf chain, no MFMA: validation only    */
+
+/* mp_encode_f32 `flags` (tuning / A-B switches; results never depend on them) */
+#define MP_FLAG_NO_DMA 1 /* stage the dictionary tile through registers instead of LDS-DMA */
+#define MP_FLAG_TA32 2   /* 32-atom workgroup tiles (64 KiB of LDS, two workgroups per CU)  */
+
+int mp_version(void);
+const char *mp_last_error(void);
+
+/*
+ * Measurement hook for bench.py (not part of the reference surface): while enabled,
+ * mp_encode_f32 brackets each of its kernel launches with hipEvents on the launch stream.
+ * mp_profile_read synchronises, then returns total milliseconds and launch counts in
+ * ms[3] / count[3] = { full correlate, incremental correlate, select+subtract }, and resets.
+ * Host pointers.  Do not enable while capturing a hipGraph.
+ */
+int mp_profile_enable(int on);
+int mp_profile_read(double *ms, int64_t *count);
+
+/* Device bytes mp_encode_f32 needs in `workspace` for this problem (0 on bad arguments). */
+size_t mp_workspace_bytes(int64_t B, int64_t N, int64_t A, int64_t L, int K, int path);
+
+/*
+ * unit_norm along the last axis: out = d / (||d||_2 + eps).
+ * Replaces modules/normalization.py:4-6 as called at modules/matchingpursuit.py:254,365,417.
+ * d, out: [A, L].  out may alias d.
+ */
+int mp_unit_norm_f32(const float *d, int64_t A, int64_t L, float eps, float *out, void *stream);
+
+/*
+ * K steps of greedy matching pursuit on a batch of independent segments.
+ * Replaces the loop body of sparse_code, modules/matchingpursuit.py:269-328: correlation of
+ * the running residual with every atom (:275-277), signed first-max argmax over atom x lag
+ * (:298-303), scaled-atom subtraction cropped at N (:304-307, :326-328).
+ *
+ *   signal     [B, N]   in   (not modified; the reference clones it, :256)
+ *   dict_unit  [A, L]   in   unit-normed dictionary (mp_unit_norm_f32)
+ *   out_atom   [B, K]   out  atom index of step k of segment b   (selection order)
+ *   out_lag    [B, K]   out  lag (sample position) of that event
+ *   out_gain   [B, K]   out  value of the feature map at the argmax (the event's gain)
+ *   out_residual [B, N] out  residual after K steps, or NULL
+ *   workspace           >= mp_workspace_bytes(...) bytes, 256-byte aligned
+ */
+int mp_encode_f32(const float *signal, int64_t B, int64_t N, const float *dict_unit, int64_t A,
+                  int64_t L, int K, int path, int flags, int64_t *out_atom, int64_t *out_lag,
+                  float *out_gain, float *out_residual, void *workspace, size_t workspace_bytes,
+                  void *stream);
+
+/*
+ * Dense feature map fm[b, a, t] = sum_k r[b, t+k] * d[a, k]  (r zero beyond N), t in [0, N).
+ * Replaces F.conv1d(F.pad(residual,(0,L)), d.view(A,1,L))[..., :N]
+ * (modules/matchingpursuit.py:275-277, :90-92; modules/conv.py:4-9).  Serves the hooks that
+ * need the dense map (visit_key_point, extract_atom_embedding, sparse_feature_map).
+ *   residual [B, N], dict_unit [A, L], fm [B, A, N]; workspace as for mp_encode_f32(K = 0).
+ */
+int mp_feature_map_f32(const float *residual, int64_t B, int64_t N, const float *dict_unit,
+                       int64_t A, int64_t L, float *fm, void *workspace, size_t workspace_bytes,
+                       void *stream);
+
+/*
+ * Decoder: out[batch[e], lag[e] + i] += dict_unit[atom[e], i] * gain[e], i < L, cropped to
+ * [0, N); events of one segment are applied in array order (bitwise reproducible).
+ * Replaces scatter_segments over encoder events, modules/matchingpursuit.py:20-58.
+ *   atom, batch, lag [n_events] int64; gain [n_events]; out [B, N] (accumulated into).
+ */
+int mp_scatter_f32(const int64_t *atom, const int64_t *batch, const int64_t *lag, const float *gain,
+                   int64_t n_events, const float *dict_unit, int64_t A, int64_t L, float *out,
+                   int64_t B, int64_t N, void *stream);
+
+/*
+ * General scatter_segments: out[batch[e], lag[e] + i] += rows[e, i]  (rows [n_events, L]).
+ * Replaces modules/matchingpursuit.py:20-58 for arbitrary event payloads (e.g. the
+ * re-scaled new atoms of dictionary_learning_step, :408-414).
+ */
+int mp_scatter_rows_f32(const float *rows, const int64_t *batch, const int64_t *lag,
+                        int64_t n_events, int64_t L, float *out, int64_t B, int64_t N,
+                        void *stream);
+
+/*
+ * gather_segments + sum over instances (modules/matchingpursuit.py:369-378, :400-401):
+ *   out[i] = sum_e x[batch[e], lag[e] + i]   i < L, x read as zero beyond N,
+ * accumulated in fp64 in event order, rounded once to fp32.  This [L] vector is the only
+ * cross-segment quantity of dictionary_learning_step, i.e. what a multi-GPU run all-reduces.
+ */
+int mp_gather_sum_f32(const float *x, int64_t B, int64_t N, const int64_t *batch,
+                      const int64_t *lag, int64_t n_events, int64_t L, double *out, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MPCORE_H */

@@ -1,0 +1,770 @@
+// mpcore.hip -- greedy matching-pursuit encoder for MI355X (gfx950 / CDNA4).  C ABI: include/mpcore.h
+//
+// Path replaced: the loop body of sparse_code, /root/reference/modules/matchingpursuit.py:269-328.
+//
+// Design:
+//   * The A x N feature map is never materialised.  The (atom, lag) plane of every segment is cut
+//     into cells of TA atoms x 64 lags; a correlate kernel computes one cell per wavefront on the
+//     fp32 matrix cores (v_mfma_f32_32x32x2_f32, which is bit for bit an ascending-k fmaf chain) and
+//     keeps only the cell's signed maximum as a 64-bit key (ordered value | inverted flat index).
+//   * A select kernel reduces a segment's keys (= torch.max's first-occurrence argmax), records the
+//     event, subtracts gain * atom from the residual, and marks the cells the subtraction touched.
+//   * MP_PATH_DIRECT recomputes every cell each iteration (what the reference does);
+//     MP_PATH_INCREMENTAL recomputes only the marked cells.  A cell's value depends only on the
+//     residual samples under it, so both select identical events, bit for bit.
+//   * The dictionary tile of a workgroup is staged once into LDS (up to 128 KiB of the 160 KiB),
+//     pre-swizzled by a prep kernel so that MFMA B-operands for four k-steps come from one
+//     conflict-free ds_read_b128; the residual window is read as a Toeplitz A-operand straight
+//     from LDS with ds_read_b32 at immediate offsets.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <mutex>
+#include <vector>
+
+#include "mpcore.h"
+
+namespace {
+
+thread_local char g_err[512] = "";
+
+int fail(int code, const char *fmt, const char *detail = "") {
+    snprintf(g_err, sizeof(g_err), fmt, detail);
+    return code;
+}
+
+#define HIP_TRY(expr)                                                         \
+    do {                                                                      \
+        hipError_t e_ = (expr);                                               \
+        if (e_ != hipSuccess) return fail(MP_ERR_HIP, #expr ": %s", hipGetErrorString(e_)); \
+    } while (0)
+
+// ------------------------------------------------------------------------------------------------
+// Optional per-kernel timing (bench.py): hipEvents recorded on the launch stream around every
+// correlate / select launch of mp_encode_f32.  Off by default; never used while capturing a graph.
+// ------------------------------------------------------------------------------------------------
+enum { PROF_CORR_FULL = 0, PROF_CORR_INC = 1, PROF_SELECT = 2, PROF_KINDS = 3 };
+struct ProfSpan { hipEvent_t a, b; int kind; };
+struct Profiler {
+    bool on = false;
+    std::vector<ProfSpan> spans;
+    std::vector<hipEvent_t> pool;
+    hipEvent_t get() {
+        if (!pool.empty()) { hipEvent_t e = pool.back(); pool.pop_back(); return e; }
+        hipEvent_t e = nullptr;
+        if (hipEventCreate(&e) != hipSuccess) return nullptr;
+        return e;
+    }
+    void begin(int kind, hipStream_t st) {
+        if (!on) return;
+        ProfSpan s{get(), get(), kind};
+        if (!s.a || !s.b) return;
+        (void)hipEventRecord(s.a, st);
+        spans.push_back(s);
+    }
+    void end(hipStream_t st) {
+        if (!on || spans.empty()) return;
+        (void)hipEventRecord(spans.back().b, st);
+    }
+};
+Profiler g_prof;
+std::mutex g_prof_mu;
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned long long u64;
+
+constexpr int LAGS_PER_WAVE = 64;   // one cell = TA atoms x 64 lags, owned by one wavefront
+constexpr int WAVES = 4;            // wavefronts per workgroup
+constexpr int WG_LAGS = LAGS_PER_WAVE * WAVES;
+constexpr int KC_MAX = 512;         // atom samples staged in LDS per chunk
+
+__host__ __device__ inline int64_t round_up(int64_t x, int64_t m) { return (x + m - 1) / m * m; }
+
+// ------------------------------------------------------------------------------------------------
+// Geometry shared by host and device
+// ------------------------------------------------------------------------------------------------
+struct Geom {
+    int64_t B, N, A, L;
+    int TA;        // atoms per cell
+    int NAT;       // atom tiles  = ceil(A / TA)
+    int NBLK;      // lag blocks  = ceil(N / 64)
+    int KC;        // k chunk (multiple of 16, <= KC_MAX)
+    int NCH;       // k chunks
+    int Lpp;       // NCH * KC  (dictionary k extent incl. zero padding)
+    int64_t Ns;    // residual row stride in floats (zero padded past N)
+    int NGRP_FULL; // workgroups along lags for a full pass
+    int NGRP_INC;  // workgroups along lags for a dirty window
+};
+
+Geom make_geom(int64_t B, int64_t N, int64_t A, int64_t L, int TA) {
+    Geom g;
+    g.B = B; g.N = N; g.A = A; g.L = L; g.TA = TA;
+    g.NAT = (int)((A + TA - 1) / TA);
+    g.NBLK = (int)((N + LAGS_PER_WAVE - 1) / LAGS_PER_WAVE);
+    int Lp = (int)round_up(L, 16);  // k8 groups are consumed in pairs
+    g.KC = Lp < KC_MAX ? Lp : KC_MAX;
+    g.NCH = (Lp + g.KC - 1) / g.KC;
+    g.Lpp = g.NCH * g.KC;
+    g.Ns = round_up((int64_t)g.NBLK * LAGS_PER_WAVE + WG_LAGS + g.Lpp + 64, 64);
+    g.NGRP_FULL = (g.NBLK + WAVES - 1) / WAVES;
+    // a subtraction at lag p changes lags [p-L+1, p+L-1]: at most this many 64-lag blocks
+    int nb = (int)((2 * L - 2) / LAGS_PER_WAVE) + 2;
+    if (nb > g.NBLK) nb = g.NBLK;
+    g.NGRP_INC = (nb + WAVES - 1) / WAVES;
+    return g;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Keys: max over keys == torch.max (signed value, first flat index on ties)
+// ------------------------------------------------------------------------------------------------
+__device__ inline unsigned ord_f32(float f) {
+    unsigned u = __float_as_uint(f + 0.0f);  // -0.0 -> +0.0 (torch compares them equal)
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ inline float unord_f32(unsigned o) {
+    unsigned u = (o & 0x80000000u) ? (o & 0x7fffffffu) : ~o;
+    return __uint_as_float(u);
+}
+__device__ inline u64 make_key(float v, unsigned flat) {
+    return ((u64)ord_f32(v) << 32) | (u64)(0xffffffffu - flat);
+}
+
+__device__ inline u64 wave_max_u64(u64 k) {
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        unsigned lo = __shfl_xor((unsigned)k, off, 64);
+        unsigned hi = __shfl_xor((unsigned)(k >> 32), off, 64);
+        u64 o = ((u64)hi << 32) | lo;
+        k = o > k ? o : k;
+    }
+    return k;
+}
+
+// ------------------------------------------------------------------------------------------------
+// unit_norm  (modules/normalization.py:4-6): one thread per atom, fp64 sequential sum of squares so
+// that the CPU oracle reproduces it bit for bit.  A*L is tiny next to one correlation.
+// ------------------------------------------------------------------------------------------------
+__global__ void unit_norm_kernel(const float *__restrict__ d, int64_t A, int64_t L, float eps,
+                                 float *__restrict__ out) {
+    int64_t a = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (a >= A) return;
+    const float *row = d + a * L;
+    double s = 0.0;
+    for (int64_t k = 0; k < L; ++k) {
+        double x = (double)row[k];
+        s += x * x;
+    }
+    float n = __fsqrt_rn((float)s);
+    float den = __fadd_rn(n, eps);
+    float *orow = out + a * L;
+    for (int64_t k = 0; k < L; ++k) orow[k] = __fdiv_rn(row[k], den);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Dictionary image: [atom tile][k chunk][k8 group][k parity][atom in tile][4] floats, so that lane
+// (n = lane & 31, h = lane >> 5) of a wavefront reads, with ONE 16-byte LDS load at
+//   ((g * 2 + h) * TA + n) * 16 bytes,
+// the B operands d[n][8g + h], d[n][8g + 2 + h], d[n][8g + 4 + h], d[n][8g + 6 + h] of the four
+// consecutive v_mfma_f32_32x32x2_f32 k-steps of group g -- ascending k, lanes contiguous (no bank
+// conflicts).  Atoms >= A and samples >= L are zero (an fma with a zero product is exact).
+// ------------------------------------------------------------------------------------------------
+__global__ void dict_image_kernel(const float *__restrict__ du, int64_t A, int64_t L, int TA, int KC,
+                                  int NCH, int NAT, float *__restrict__ img) {
+    int64_t total = (int64_t)NAT * NCH * KC * TA;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total;
+         e += (int64_t)gridDim.x * blockDim.x) {
+        int q = (int)(e & 3);
+        int64_t r = e >> 2;
+        int n = (int)(r % TA); r /= TA;
+        int h = (int)(r & 1); r >>= 1;
+        int g = (int)(r % (KC / 8)); r /= (KC / 8);
+        int c = (int)(r % NCH);
+        int tile = (int)(r / NCH);
+        int64_t a = (int64_t)tile * TA + n;
+        int64_t k = (int64_t)c * KC + g * 8 + q * 2 + h;
+        img[e] = (a < A && k < L) ? du[a * L + k] : 0.0f;
+    }
+}
+
+__global__ void init_residual_kernel(const float *__restrict__ signal, int64_t N, int64_t Ns,
+                                     float *__restrict__ res) {
+    int64_t b = blockIdx.y;
+    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < Ns;
+         t += (int64_t)gridDim.x * blockDim.x)
+        res[b * Ns + t] = t < N ? signal[b * N + t] : 0.0f;
+}
+
+__global__ void copy_residual_kernel(const float *__restrict__ res, int64_t N, int64_t Ns,
+                                     float *__restrict__ out) {
+    int64_t b = blockIdx.y;
+    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < N;
+         t += (int64_t)gridDim.x * blockDim.x)
+        out[b * N + t] = res[b * Ns + t];
+}
+
+// ------------------------------------------------------------------------------------------------
+// Correlate: one workgroup = (segment b, atom tile, 4 consecutive 64-lag blocks), one wavefront per
+// block.  GEMM view per wavefront: C[64 lags x TA atoms] = R[64 x L] (Toeplitz: R[t][k] = r[t+k])
+// times D^T[L x TA], on v_mfma_f32_32x32x2_f32 (A operand = residual, B operand = dictionary).
+//   A operand lane map: lane l holds R[row l&31][k l>>5]  -> LDS word  win[t + (l&31) + (l>>5) + k]
+//   B operand lane map: lane l holds D[k l>>5][col l&31]  -> component j of the 16-byte image word
+//   C/D: col = lane & 31 (atom), row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5) (lag)
+// Every product chain is ascending in k: bit-identical to the oracle's fmaf chain.
+// STORE_FM: additionally write the dense map (hooks that need it); keys are still produced.
+// ------------------------------------------------------------------------------------------------
+template <int TA, bool STORE_FM, bool DMA>
+__global__ __launch_bounds__(256) void correlate_mfma_kernel(
+    const float *__restrict__ res, const float *__restrict__ img, const int *__restrict__ dirty,
+    u64 *__restrict__ keys, float *__restrict__ fm, int64_t N, int64_t A, int64_t Ns, int NBLK, int NAT,
+    int KC, int NCH) {
+    constexpr int NT = TA / 32;  // 32-atom sub-tiles per wavefront
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float *img_s = reinterpret_cast<float *>(smem);                 // KC * TA floats
+    float *win_s = img_s + (size_t)KC * TA;                         // KC + WG_LAGS floats
+
+    const int b = blockIdx.z;
+    const int tile = blockIdx.y;
+    int first = 0, count = NBLK;
+    if (dirty) {
+        first = dirty[2 * b];
+        count = dirty[2 * b + 1];
+    }
+    const int grp0 = blockIdx.x * WAVES;  // first block of this workgroup, relative to `first`
+    if (grp0 >= count) return;            // uniform: whole workgroup has nothing to do
+
+    const int tid = threadIdx.x;
+    const int w = tid >> 6;
+    const int lane = tid & 63;
+    const int i = lane & 31;
+    const int h = lane >> 5;
+    const int blk0 = first + grp0;
+    const int64_t tbase = (int64_t)blk0 * LAGS_PER_WAVE;
+    const bool active = (grp0 + w) < count;  // wave-uniform
+
+    f32x16 acc[2][NT];
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[s][nt][r] = 0.0f;
+
+    const float *res_b = res + (int64_t)b * Ns;
+    const f32x4 *img_g = reinterpret_cast<const f32x4 *>(img) + (size_t)tile * NCH * (KC * TA / 4);
+
+    for (int c = 0; c < NCH; ++c) {
+        if (c > 0) __syncthreads();  // previous chunk fully consumed
+        // ---- stage the dictionary chunk (already in LDS order) and the residual window ------------
+        {
+            const f32x4 *src = img_g + (size_t)c * (KC * TA / 4);
+            const int n4 = KC * TA / 4;  // multiple of 256: KC % 16 == 0, TA % 32 == 0
+            if (DMA) {
+                // LDS-DMA: each wave-instruction moves 64 x 16 B = 1 KiB, LDS address = wave-uniform
+                // base + lane * 16 (the image is linear in both memories, so no swizzle is needed).
+                for (int e0 = w * 64; e0 < n4; e0 += 256) {
+                    __builtin_amdgcn_global_load_lds(
+                        (const __attribute__((address_space(1))) void *)(src + e0 + lane),
+                        (__attribute__((address_space(3))) void *)(img_s + (size_t)e0 * 4),
+                        16, 0, 0);
+                }
+            } else {
+                f32x4 *dst = reinterpret_cast<f32x4 *>(img_s);
+                for (int e0 = tid; e0 < n4; e0 += 256 * 8) {
+                    f32x4 tmp[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) tmp[u] = src[e0 + u * 256];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) dst[e0 + u * 256] = tmp[u];
+                }
+            }
+            const f32x4 *wsrc = reinterpret_cast<const f32x4 *>(res_b + tbase + (int64_t)c * KC);
+            f32x4 *wdst = reinterpret_cast<f32x4 *>(win_s);
+            const int w4 = (KC + WG_LAGS) / 4;
+            for (int e = tid; e < w4; e += 256) wdst[e] = wsrc[e];
+        }
+        __syncthreads();  // hipcc drains vmcnt(0) here while LDS-DMA is outstanding
+        if (active) {
+            const f32x4 *bp = reinterpret_cast<const f32x4 *>(img_s) + h * TA + i;
+            const float *ap = win_s + w * LAGS_PER_WAVE + i + h;
+            const int ngrp = KC / 8;  // even
+            // software pipeline, two k8-groups per trip: operands of the next group are in flight
+            // while the 8*NT MFMAs (512*NT cycles) of the current one issue.
+            f32x4 bA[NT], bB[NT];
+            float aA[8], aB[8];
+#define MP_LOAD_GROUP(BQ, AQ, G)                                                        \
+    {                                                                                   \
+        _Pragma("unroll") for (int nt = 0; nt < NT; ++nt) BQ[nt] = bp[(size_t)(G) * 2 * TA + nt * 32]; \
+        _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                 \
+            AQ[2 * j] = ap[(G) * 8 + 2 * j];                                            \
+            AQ[2 * j + 1] = ap[(G) * 8 + 2 * j + 32];                                   \
+        }                                                                               \
+    }
+#define MP_MFMA_GROUP(BQ, AQ)                                                           \
+    {                                                                                   \
+        _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                 \
+            _Pragma("unroll") for (int nt = 0; nt < NT; ++nt) {                         \
+                acc[0][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(AQ[2 * j], BQ[nt][j], acc[0][nt], 0, 0, 0);     \
+                acc[1][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(AQ[2 * j + 1], BQ[nt][j], acc[1][nt], 0, 0, 0); \
+            }                                                                           \
+        }                                                                               \
+    }
+            MP_LOAD_GROUP(bA, aA, 0)
+            for (int g = 0; g < ngrp; g += 2) {
+                MP_LOAD_GROUP(bB, aB, g + 1)
+                MP_MFMA_GROUP(bA, aA)
+                MP_LOAD_GROUP(bA, aA, g + 2)  // last trip reads the LDS pad: loaded, never used
+                MP_MFMA_GROUP(bB, aB)
+                // pin the issue order: a group's LDS reads go out ahead of the PREVIOUS group's
+                // MFMAs, so their latency hides under 8*NT x 64 cycles of matrix work
+                __builtin_amdgcn_sched_group_barrier(0x100, NT + 4, 0);  // DS reads (ds_read2 pairs)
+                __builtin_amdgcn_sched_group_barrier(0x008, 8 * NT, 0);  // MFMA
+                __builtin_amdgcn_sched_group_barrier(0x100, NT + 4, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 8 * NT, 0);
+            }
+#undef MP_LOAD_GROUP
+#undef MP_MFMA_GROUP
+        }
+    }
+    if (!active) return;
+
+    // ---- epilogue: signed max of the cell, first flat index on ties -------------------------------
+    const int blk = blk0 + w;
+    const int64_t t0 = (int64_t)blk * LAGS_PER_WAVE;
+    float m = -INFINITY;
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            const int64_t atom = (int64_t)tile * TA + nt * 32 + i;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int64_t lag = t0 + s * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                const bool ok = (lag < N) && (atom < A);
+                float v = ok ? acc[s][nt][r] : -INFINITY;
+                acc[s][nt][r] = v;
+                m = fmaxf(m, v);
+            }
+        }
+    unsigned best = 0xffffffffu;
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            const int64_t atom = (int64_t)tile * TA + nt * 32 + i;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int64_t lag = t0 + s * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                const unsigned flat = (unsigned)(atom * N + lag);
+                const bool hit = (acc[s][nt][r] == m) && (lag < N) && (atom < A);
+                best = (hit && flat < best) ? flat : best;
+            }
+        }
+    u64 key = best == 0xffffffffu ? 0ull : make_key(m, best);
+    key = wave_max_u64(key);
+    if (lane == 0) keys[((int64_t)b * NBLK + blk) * NAT + tile] = key;
+
+    if (STORE_FM) {
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                const int64_t atom = (int64_t)tile * TA + nt * 32 + i;
+                if (atom < A) {
+                    float *row = fm + ((int64_t)b * A + atom) * N;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int64_t lag = t0 + s * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                        if (lag < N) row[lag] = acc[s][nt][r];
+                    }
+                }
+            }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Validation kernel (MP_PATH_NAIVE): one thread per lag, plain fmaf chain from global memory,
+// cells of 1 atom x 64 lags.  Same keys contract; no MFMA, no LDS.
+// ------------------------------------------------------------------------------------------------
+__global__ void correlate_naive_kernel(const float *__restrict__ res, const float *__restrict__ du,
+                                       const int *__restrict__ dirty, u64 *__restrict__ keys,
+                                       float *__restrict__ fm, int64_t N, int64_t A, int64_t L,
+                                       int64_t Ns, int NBLK) {
+    const int b = blockIdx.z;
+    const int64_t atom = blockIdx.y;
+    int first = 0, count = NBLK;
+    if (dirty) {
+        first = dirty[2 * b];
+        count = dirty[2 * b + 1];
+    }
+    if ((int)blockIdx.x >= count) return;
+    const int blk = first + blockIdx.x;
+    const int lane = threadIdx.x;
+    const int64_t lag = (int64_t)blk * LAGS_PER_WAVE + lane;
+    const float *r = res + (int64_t)b * Ns + lag;
+    const float *d = du + atom * L;
+    float acc = 0.0f;
+    for (int64_t k = 0; k < L; ++k) acc = __fmaf_rn(r[k], d[k], acc);
+    u64 key = lag < N ? make_key(acc, (unsigned)(atom * N + lag)) : 0ull;
+    key = wave_max_u64(key);
+    if (lane == 0) keys[((int64_t)b * NBLK + blk) * A + atom] = key;
+    if (fm && lag < N) fm[((int64_t)b * A + atom) * N + lag] = acc;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Select: argmax over a segment's cell keys, record the event, subtract gain * atom (cropped at N,
+// two roundings like `residual -= d[atom] * value`, matchingpursuit.py:305,:328), mark dirty blocks.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void select_subtract_kernel(
+    const u64 *__restrict__ keys, int64_t n_keys, float *__restrict__ res, const float *__restrict__ du,
+    int *__restrict__ dirty, int64_t *__restrict__ out_atom, int64_t *__restrict__ out_lag,
+    float *__restrict__ out_gain, int64_t N, int64_t L, int64_t Ns, int NBLK, int K, int k) {
+    __shared__ u64 s_key[4];
+    const int b = blockIdx.x;
+    const int tid = threadIdx.x;
+    const u64 *kb = keys + (int64_t)b * n_keys;
+    u64 best = 0;
+    for (int64_t e = tid; e < n_keys; e += 256) {
+        u64 v = kb[e];
+        best = v > best ? v : best;
+    }
+    best = wave_max_u64(best);
+    if ((tid & 63) == 0) s_key[tid >> 6] = best;
+    __syncthreads();
+    best = s_key[0];
+#pragma unroll
+    for (int q = 1; q < 4; ++q) best = s_key[q] > best ? s_key[q] : best;
+
+    const unsigned flat = 0xffffffffu - (unsigned)(best & 0xffffffffull);
+    const float gain = unord_f32((unsigned)(best >> 32));
+    const int64_t atom = (int64_t)(flat / (u64)N);
+    const int64_t lag = (int64_t)(flat % (u64)N);
+    if (tid == 0) {
+        out_atom[(int64_t)b * K + k] = atom;
+        out_lag[(int64_t)b * K + k] = lag;
+        out_gain[(int64_t)b * K + k] = gain;
+        if (dirty) {
+            int64_t lo = lag - L + 1; if (lo < 0) lo = 0;
+            int64_t hi = lag + L - 1; if (hi > N - 1) hi = N - 1;
+            const int fb = (int)(lo / LAGS_PER_WAVE), lb = (int)(hi / LAGS_PER_WAVE);
+            dirty[2 * b] = fb;
+            dirty[2 * b + 1] = lb - fb + 1;
+        }
+    }
+    const int64_t len = (N - lag) < L ? (N - lag) : L;
+    float *r = res + (int64_t)b * Ns + lag;
+    const float *d = du + atom * L;
+    for (int64_t s = tid; s < len; s += 256) r[s] = __fsub_rn(r[s], __fmul_rn(d[s], gain));
+}
+
+__global__ void fill_dirty_kernel(int *dirty, int64_t B, int first, int count) {
+    int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (b < B) {
+        dirty[2 * b] = first;
+        dirty[2 * b + 1] = count;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// scatter_segments (modules/matchingpursuit.py:20-58): one workgroup per segment walks the event
+// list in order; events of a segment may overlap, so they are applied one after another.
+// ------------------------------------------------------------------------------------------------
+template <bool ROWS>
+__global__ __launch_bounds__(256) void scatter_kernel(const float *__restrict__ rows,
+                                                      const int64_t *__restrict__ atom,
+                                                      const int64_t *__restrict__ batch,
+                                                      const int64_t *__restrict__ lag,
+                                                      const float *__restrict__ gain, int64_t n_events,
+                                                      const float *__restrict__ du, int64_t L,
+                                                      float *__restrict__ out, int64_t N) {
+    const int64_t b = blockIdx.x;
+    float *o = out + b * N;
+    for (int64_t e = 0; e < n_events; ++e) {
+        if (batch[e] != b) continue;  // uniform across the workgroup
+        const int64_t p = lag[e];
+        const float *src = ROWS ? rows + e * L : du + atom[e] * L;
+        const float g = ROWS ? 1.0f : gain[e];
+        for (int64_t s = threadIdx.x; s < L; s += 256) {
+            const int64_t t = p + s;
+            if (t >= 0 && t < N) {
+                const float v = ROWS ? src[s] : __fmul_rn(src[s], g);
+                o[t] = __fadd_rn(o[t], v);
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// gather_segments + sum over instances (modules/matchingpursuit.py:369-378, :400-401)
+__global__ void gather_sum_kernel(const float *__restrict__ x, int64_t N, const int64_t *__restrict__ batch,
+                                  const int64_t *__restrict__ lag, int64_t n_events, int64_t L,
+                                  double *__restrict__ out) {
+    int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= L) return;
+    double acc = 0.0;
+    for (int64_t e = 0; e < n_events; ++e) {
+        const int64_t t = lag[e] + s;
+        if (t >= 0 && t < N) acc += (double)x[batch[e] * N + t];
+    }
+    out[s] = acc;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Workspace carving (all offsets multiples of 256 bytes)
+// ------------------------------------------------------------------------------------------------
+struct Workspace {
+    float *res;
+    float *img;
+    u64 *keys;
+    int *dirty;
+    size_t bytes;
+};
+
+Workspace carve(const Geom &g, int path, char *base) {
+    Workspace w;
+    size_t off = 0;
+    auto take = [&](size_t n) {
+        size_t o = off;
+        off += (size_t)round_up((int64_t)n, 256);
+        return o;
+    };
+    const bool naive = path == MP_PATH_NAIVE;
+    size_t o_res = take((size_t)g.B * g.Ns * sizeof(float));
+    size_t o_img = take(naive ? 0 : (size_t)g.NAT * g.NCH * g.KC * g.TA * sizeof(float));
+    size_t cells = naive ? (size_t)g.A : (size_t)g.NAT;
+    size_t o_keys = take((size_t)g.B * g.NBLK * cells * sizeof(u64));
+    size_t o_dirty = take((size_t)g.B * 2 * sizeof(int));
+    w.res = reinterpret_cast<float *>(base + o_res);
+    w.img = reinterpret_cast<float *>(base + o_img);
+    w.keys = reinterpret_cast<u64 *>(base + o_keys);
+    w.dirty = reinterpret_cast<int *>(base + o_dirty);
+    w.bytes = off;
+    return w;
+}
+
+int check_shape(int64_t B, int64_t N, int64_t A, int64_t L, int K) {
+    if (B < 0 || N <= 0 || A <= 0 || L <= 0 || K < 0) return fail(MP_ERR_ARG, "bad shape%s");
+    if (B > 65535) return fail(MP_ERR_ARG, "batch > 65535 per call: split the batch%s");
+    if ((unsigned long long)A * (unsigned long long)N > 0xfffffffeull)
+        return fail(MP_ERR_ARG, "A * N must be < 2^32 - 1%s");
+    if (L > (1 << 24)) return fail(MP_ERR_ARG, "atom size too large%s");
+    return MP_OK;
+}
+
+// image + window + the pad the pipelined loop's last (unused) prefetch may touch
+size_t lds_bytes(const Geom &g) {
+    return ((size_t)g.KC * g.TA + g.KC + WG_LAGS + 16) * sizeof(float) + (size_t)(g.TA + 64) * 16;
+}
+
+template <int TA, bool STORE_FM, bool DMA>
+int launch_correlate_t(const Geom &g, const Workspace &w, const int *dirty, int ngrp, float *fm,
+                       hipStream_t st) {
+    auto kern = correlate_mfma_kernel<TA, STORE_FM, DMA>;
+    const size_t lds = lds_bytes(g);
+    static thread_local size_t configured = 0;
+    if (lds > configured) {
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        configured = lds;
+    }
+    dim3 grid(ngrp, g.NAT, (unsigned)g.B);
+    hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, w.res, w.img, dirty, w.keys, fm, g.N, g.A, g.Ns,
+                       g.NBLK, g.NAT, g.KC, g.NCH);
+    HIP_TRY(hipGetLastError());
+    return MP_OK;
+}
+
+template <bool STORE_FM>
+int launch_correlate(const Geom &g, const Workspace &w, const int *dirty, int ngrp, float *fm, int flags,
+                     hipStream_t st) {
+    const bool dma = !(flags & MP_FLAG_NO_DMA);
+    if (g.TA == 32)
+        return dma ? launch_correlate_t<32, STORE_FM, true>(g, w, dirty, ngrp, fm, st)
+                   : launch_correlate_t<32, STORE_FM, false>(g, w, dirty, ngrp, fm, st);
+    return dma ? launch_correlate_t<64, STORE_FM, true>(g, w, dirty, ngrp, fm, st)
+               : launch_correlate_t<64, STORE_FM, false>(g, w, dirty, ngrp, fm, st);
+}
+
+int tile_atoms(int flags) { return (flags & MP_FLAG_TA32) ? 32 : 64; }
+
+int launch_naive(const Geom &g, const Workspace &w, const float *du, const int *dirty, int nblk_grid,
+                 float *fm, hipStream_t st) {
+    dim3 grid(nblk_grid, (unsigned)g.A, (unsigned)g.B);
+    hipLaunchKernelGGL(correlate_naive_kernel, grid, dim3(64), 0, st, w.res, du, dirty, w.keys, fm, g.N,
+                       g.A, g.L, g.Ns, g.NBLK);
+    HIP_TRY(hipGetLastError());
+    return MP_OK;
+}
+
+int stage_inputs(const Geom &g, const Workspace &w, int path, const float *signal, const float *du,
+                 hipStream_t st) {
+    {
+        dim3 grid((unsigned)((g.Ns + 255) / 256 < 1024 ? (g.Ns + 255) / 256 : 1024), (unsigned)g.B);
+        hipLaunchKernelGGL(init_residual_kernel, grid, dim3(256), 0, st, signal, g.N, g.Ns, w.res);
+        HIP_TRY(hipGetLastError());
+    }
+    if (path != MP_PATH_NAIVE) {
+        int64_t total = (int64_t)g.NAT * g.NCH * g.KC * g.TA;
+        unsigned blocks = (unsigned)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+        hipLaunchKernelGGL(dict_image_kernel, dim3(blocks), dim3(256), 0, st, du, g.A, g.L, g.TA, g.KC,
+                           g.NCH, g.NAT, w.img);
+        HIP_TRY(hipGetLastError());
+    }
+    return MP_OK;
+}
+
+}  // namespace
+
+// =================================================================================================
+// C ABI
+// =================================================================================================
+extern "C" {
+
+int mp_version(void) { return 1; }
+
+const char *mp_last_error(void) { return g_err; }
+
+size_t mp_workspace_bytes(int64_t B, int64_t N, int64_t A, int64_t L, int K, int path) {
+    if (check_shape(B, N, A, L, K) != MP_OK) return 0;
+    size_t b64 = carve(make_geom(B, N, A, L, 64), path, nullptr).bytes;
+    size_t b32 = carve(make_geom(B, N, A, L, 32), path, nullptr).bytes;
+    return b64 > b32 ? b64 : b32;
+}
+
+int mp_profile_enable(int on) {
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    g_prof.on = on != 0;
+    return MP_OK;
+}
+
+int mp_profile_read(double *ms, int64_t *count) {
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    if (!ms || !count) return fail(MP_ERR_ARG, "mp_profile_read: null output%s");
+    for (int q = 0; q < PROF_KINDS; ++q) { ms[q] = 0.0; count[q] = 0; }
+    for (ProfSpan &sp : g_prof.spans) {
+        HIP_TRY(hipEventSynchronize(sp.b));
+        float t = 0.f;
+        HIP_TRY(hipEventElapsedTime(&t, sp.a, sp.b));
+        ms[sp.kind] += (double)t;
+        count[sp.kind] += 1;
+        g_prof.pool.push_back(sp.a);
+        g_prof.pool.push_back(sp.b);
+    }
+    g_prof.spans.clear();
+    return MP_OK;
+}
+
+int mp_unit_norm_f32(const float *d, int64_t A, int64_t L, float eps, float *out, void *stream) {
+    if (!d || !out || A <= 0 || L <= 0) return fail(MP_ERR_ARG, "mp_unit_norm_f32: bad arguments%s");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    hipLaunchKernelGGL(unit_norm_kernel, dim3((unsigned)((A + 63) / 64)), dim3(64), 0, st, d, A, L, eps,
+                       out);
+    HIP_TRY(hipGetLastError());
+    return MP_OK;
+}
+
+int mp_encode_f32(const float *signal, int64_t B, int64_t N, const float *dict_unit, int64_t A,
+                  int64_t L, int K, int path, int flags, int64_t *out_atom, int64_t *out_lag,
+                  float *out_gain, float *out_residual, void *workspace, size_t workspace_bytes,
+                  void *stream) {
+    int rc = check_shape(B, N, A, L, K);
+    if (rc) return rc;
+    if (path == MP_PATH_FFT) return fail(MP_ERR_UNSUPPORTED, "MP_PATH_FFT is not built yet%s");
+    if (path != MP_PATH_DIRECT && path != MP_PATH_INCREMENTAL && path != MP_PATH_NAIVE)
+        return fail(MP_ERR_ARG, "unknown path%s");
+    if (B == 0) return MP_OK;
+    if (!signal || !dict_unit || !workspace) return fail(MP_ERR_ARG, "null pointer%s");
+    if (K > 0 && (!out_atom || !out_lag || !out_gain)) return fail(MP_ERR_ARG, "null output%s");
+    if (reinterpret_cast<uintptr_t>(workspace) % 256) return fail(MP_ERR_WORKSPACE, "workspace not 256-byte aligned%s");
+    Geom g = make_geom(B, N, A, L, tile_atoms(flags));
+    Workspace w = carve(g, path, static_cast<char *>(workspace));
+    if (w.bytes > workspace_bytes) return fail(MP_ERR_WORKSPACE, "workspace too small%s");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+
+    rc = stage_inputs(g, w, path, signal, dict_unit, st);
+    if (rc) return rc;
+
+    const bool naive = path == MP_PATH_NAIVE;
+    const bool incremental = path == MP_PATH_INCREMENTAL;
+    const int64_t n_keys = (int64_t)g.NBLK * (naive ? g.A : g.NAT);
+    for (int k = 0; k < K; ++k) {
+        const bool full = (k == 0) || !incremental;
+        const int *dirty = full ? nullptr : w.dirty;
+        g_prof.begin(full ? PROF_CORR_FULL : PROF_CORR_INC, st);
+        if (naive)
+            rc = launch_naive(g, w, dict_unit, dirty, g.NBLK, nullptr, st);
+        else
+            rc = launch_correlate<false>(g, w, dirty, full ? g.NGRP_FULL : g.NGRP_INC, nullptr, flags, st);
+        g_prof.end(st);
+        if (rc) return rc;
+        g_prof.begin(PROF_SELECT, st);
+        hipLaunchKernelGGL(select_subtract_kernel, dim3((unsigned)B), dim3(256), 0, st, w.keys, n_keys,
+                           w.res, dict_unit, incremental ? w.dirty : nullptr, out_atom, out_lag, out_gain,
+                           N, L, g.Ns, g.NBLK, K, k);
+        g_prof.end(st);
+        HIP_TRY(hipGetLastError());
+    }
+    if (out_residual) {
+        dim3 grid((unsigned)((N + 255) / 256 < 1024 ? (N + 255) / 256 : 1024), (unsigned)B);
+        hipLaunchKernelGGL(copy_residual_kernel, grid, dim3(256), 0, st, w.res, N, g.Ns, out_residual);
+        HIP_TRY(hipGetLastError());
+    }
+    return MP_OK;
+}
+
+int mp_feature_map_f32(const float *residual, int64_t B, int64_t N, const float *dict_unit,
+                       int64_t A, int64_t L, float *fm, void *workspace, size_t workspace_bytes,
+                       void *stream) {
+    int rc = check_shape(B, N, A, L, 0);
+    if (rc) return rc;
+    if (B == 0) return MP_OK;
+    if (!residual || !dict_unit || !fm || !workspace) return fail(MP_ERR_ARG, "null pointer%s");
+    if (reinterpret_cast<uintptr_t>(workspace) % 256) return fail(MP_ERR_WORKSPACE, "workspace not 256-byte aligned%s");
+    Geom g = make_geom(B, N, A, L, 64);
+    Workspace w = carve(g, MP_PATH_DIRECT, static_cast<char *>(workspace));
+    if (w.bytes > workspace_bytes) return fail(MP_ERR_WORKSPACE, "workspace too small%s");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    rc = stage_inputs(g, w, MP_PATH_DIRECT, residual, dict_unit, st);
+    if (rc) return rc;
+    return launch_correlate<true>(g, w, nullptr, g.NGRP_FULL, fm, 0, st);
+}
+
+int mp_scatter_f32(const int64_t *atom, const int64_t *batch, const int64_t *lag, const float *gain,
+                   int64_t n_events, const float *dict_unit, int64_t A, int64_t L, float *out,
+                   int64_t B, int64_t N, void *stream) {
+    if (n_events == 0 || B == 0) return MP_OK;
+    if (!atom || !batch || !lag || !gain || !dict_unit || !out || A <= 0 || L <= 0 || N <= 0 || B < 0 ||
+        n_events < 0)
+        return fail(MP_ERR_ARG, "mp_scatter_f32: bad arguments%s");
+    hipLaunchKernelGGL(scatter_kernel<false>, dim3((unsigned)B), dim3(256), 0,
+                       static_cast<hipStream_t>(stream), nullptr, atom, batch, lag, gain, n_events, dict_unit,
+                       L, out, N);
+    HIP_TRY(hipGetLastError());
+    return MP_OK;
+}
+
+int mp_scatter_rows_f32(const float *rows, const int64_t *batch, const int64_t *lag, int64_t n_events,
+                        int64_t L, float *out, int64_t B, int64_t N, void *stream) {
+    if (n_events == 0 || B == 0) return MP_OK;
+    if (!rows || !batch || !lag || !out || L <= 0 || N <= 0 || B < 0 || n_events < 0)
+        return fail(MP_ERR_ARG, "mp_scatter_rows_f32: bad arguments%s");
+    hipLaunchKernelGGL(scatter_kernel<true>, dim3((unsigned)B), dim3(256), 0,
+                       static_cast<hipStream_t>(stream), rows, nullptr, batch, lag, nullptr, n_events, nullptr,
+                       L, out, N);
+    HIP_TRY(hipGetLastError());
+    return MP_OK;
+}
+
+int mp_gather_sum_f32(const float *x, int64_t B, int64_t N, const int64_t *batch, const int64_t *lag,
+                      int64_t n_events, int64_t L, double *out, void *stream) {
+    if (!x || !out || L <= 0 || N <= 0 || B <= 0 || n_events < 0 || (n_events > 0 && (!batch || !lag)))
+        return fail(MP_ERR_ARG, "mp_gather_sum_f32: bad arguments%s");
+    hipLaunchKernelGGL(gather_sum_kernel, dim3((unsigned)((L + 255) / 256)), dim3(256), 0,
+                       static_cast<hipStream_t>(stream), x, N, batch, lag, n_events, L, out);
+    HIP_TRY(hipGetLastError());
+    return MP_OK;
+}
+
+}  // extern "C"

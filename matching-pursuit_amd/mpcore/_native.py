@@ -1,0 +1,212 @@
+"""ctypes binding of libmpcore.so (C ABI: include/mpcore.h).
+
+There is no fallback: if the library is missing or a call fails, an exception is raised.
+PyTorch is used only as the owner of device memory and streams; every pointer handed to the
+library is `tensor.data_ptr()`.
+"""
+import ctypes
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(os.path.dirname(_HERE), "lib", "libmpcore.so")
+
+MP_PATH_DIRECT = 0
+MP_PATH_FFT = 1
+MP_PATH_INCREMENTAL = 2
+MP_PATH_NAIVE = 8
+MP_FLAG_NO_DMA = 1
+MP_FLAG_TA32 = 2
+
+EXPORTS = (
+    "mp_version", "mp_last_error", "mp_workspace_bytes", "mp_unit_norm_f32", "mp_encode_f32",
+    "mp_feature_map_f32", "mp_scatter_f32", "mp_scatter_rows_f32", "mp_gather_sum_f32",
+    "mp_profile_enable", "mp_profile_read",
+)
+
+_lib = None
+
+
+class NativeError(RuntimeError):
+    pass
+
+
+def lib():
+    """Load libmpcore.so (once).  Raises NativeError if it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise NativeError(
+                f"{LIB_PATH} not found: build it with matching-pursuit_amd/csrc/build.sh "
+                "(or python -c 'import __graft_entry__ as g; g.build()'); there is no CPU fallback")
+        L = ctypes.CDLL(LIB_PATH)
+        i64, vp, fp = ctypes.c_int64, ctypes.c_void_p, ctypes.c_float
+        L.mp_version.restype = ctypes.c_int
+        L.mp_last_error.restype = ctypes.c_char_p
+        L.mp_workspace_bytes.restype = ctypes.c_size_t
+        L.mp_workspace_bytes.argtypes = [i64, i64, i64, i64, ctypes.c_int, ctypes.c_int]
+        L.mp_unit_norm_f32.argtypes = [vp, i64, i64, fp, vp, vp]
+        L.mp_encode_f32.argtypes = [vp, i64, i64, vp, i64, i64, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                    vp, vp, vp, vp, vp, ctypes.c_size_t, vp]
+        L.mp_feature_map_f32.argtypes = [vp, i64, i64, vp, i64, i64, vp, vp, ctypes.c_size_t, vp]
+        L.mp_scatter_f32.argtypes = [vp, vp, vp, vp, i64, vp, i64, i64, vp, i64, i64, vp]
+        L.mp_scatter_rows_f32.argtypes = [vp, vp, vp, i64, i64, vp, i64, i64, vp]
+        L.mp_gather_sum_f32.argtypes = [vp, i64, i64, vp, vp, i64, i64, vp, vp]
+        for name in EXPORTS:
+            getattr(L, name)
+        _lib = L
+    return _lib
+
+
+def _check(rc, what):
+    if rc != 0:
+        raise NativeError(f"{what} failed (rc={rc}): {lib().mp_last_error().decode()}")
+
+
+def _stream(t):
+    return ctypes.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
+
+
+def _require_cuda(*tensors):
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise NativeError("libmpcore operates on device memory only: got a CPU tensor")
+
+
+def _f32(t):
+    return t.detach().to(torch.float32).contiguous()
+
+
+def _ptr(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else ctypes.c_void_p(0)
+
+
+def profile_enable(on=True):
+    _check(lib().mp_profile_enable(1 if on else 0), "mp_profile_enable")
+
+
+def profile_read():
+    """-> dict(kind -> (total_ms, launches)) for kinds corr_full, corr_inc, select; resets."""
+    ms = (ctypes.c_double * 3)()
+    cnt = (ctypes.c_int64 * 3)()
+    _check(lib().mp_profile_read(ms, cnt), "mp_profile_read")
+    return {k: (float(ms[i]), int(cnt[i])) for i, k in enumerate(("corr_full", "corr_inc", "select"))}
+
+
+def unit_norm(d, eps=1e-8):
+    d = _f32(d)
+    _require_cuda(d)
+    A, L = d.shape
+    out = torch.empty_like(d)
+    with torch.cuda.device(d.device):
+        _check(lib().mp_unit_norm_f32(_ptr(d), A, L, eps, _ptr(out), _stream(d)), "mp_unit_norm_f32")
+    return out
+
+
+def workspace_bytes(B, N, A, L, K, path):
+    n = lib().mp_workspace_bytes(B, N, A, L, K, path)
+    if n == 0 and B > 0:
+        raise NativeError(f"mp_workspace_bytes: {lib().mp_last_error().decode()}")
+    return int(n)
+
+
+def encode(signal, dict_unit, n_steps, path=MP_PATH_INCREMENTAL, flags=0, want_residual=True):
+    """signal [B,N] f32 cuda, dict_unit [A,L] f32 cuda -> (atom[B,K] i64, lag[B,K] i64,
+    gain[B,K] f32, residual[B,N] f32 | None), all on signal.device, asynchronous."""
+    signal = _f32(signal)
+    dict_unit = _f32(dict_unit)
+    _require_cuda(signal, dict_unit)
+    B, N = signal.shape
+    A, L = dict_unit.shape
+    K = int(n_steps)
+    dev = signal.device
+    atom = torch.empty((B, K), dtype=torch.int64, device=dev)
+    lag = torch.empty((B, K), dtype=torch.int64, device=dev)
+    gain = torch.empty((B, K), dtype=torch.float32, device=dev)
+    residual = torch.empty((B, N), dtype=torch.float32, device=dev) if want_residual else None
+    if B == 0:
+        return atom, lag, gain, residual
+    nbytes = workspace_bytes(B, N, A, L, K, path)
+    ws = torch.empty(nbytes + 256, dtype=torch.uint8, device=dev)
+    off = (-ws.data_ptr()) % 256
+    with torch.cuda.device(dev):
+        rc = lib().mp_encode_f32(_ptr(signal), B, N, _ptr(dict_unit), A, L, K, int(path), int(flags),
+                                 _ptr(atom), _ptr(lag), _ptr(gain), _ptr(residual),
+                                 ctypes.c_void_p(ws.data_ptr() + off), nbytes, _stream(signal))
+    _check(rc, "mp_encode_f32")
+    # the workspace must outlive the asynchronous kernels: tie it to the stream
+    ws.record_stream(torch.cuda.current_stream(dev))
+    return atom, lag, gain, residual
+
+
+def feature_map(residual, dict_unit):
+    residual = _f32(residual)
+    dict_unit = _f32(dict_unit)
+    _require_cuda(residual, dict_unit)
+    B, N = residual.shape
+    A, L = dict_unit.shape
+    dev = residual.device
+    fm = torch.empty((B, A, N), dtype=torch.float32, device=dev)
+    if B == 0:
+        return fm
+    nbytes = workspace_bytes(B, N, A, L, 0, MP_PATH_DIRECT)
+    ws = torch.empty(nbytes + 256, dtype=torch.uint8, device=dev)
+    off = (-ws.data_ptr()) % 256
+    with torch.cuda.device(dev):
+        rc = lib().mp_feature_map_f32(_ptr(residual), B, N, _ptr(dict_unit), A, L, _ptr(fm),
+                                      ctypes.c_void_p(ws.data_ptr() + off), nbytes, _stream(residual))
+    _check(rc, "mp_feature_map_f32")
+    ws.record_stream(torch.cuda.current_stream(dev))
+    return fm
+
+
+def _i64(t, dev):
+    return t.detach().to(device=dev, dtype=torch.int64).contiguous().view(-1)
+
+
+def scatter(atom, batch, lag, gain, dict_unit, out):
+    """out[B,N] += sum of gain * dict_unit[atom] at lag (in place, event order per segment)."""
+    _require_cuda(out, dict_unit)
+    assert out.dtype == torch.float32 and out.is_contiguous() and out.dim() == 2
+    dev = out.device
+    dict_unit = _f32(dict_unit)
+    atom, batch, lag = _i64(atom, dev), _i64(batch, dev), _i64(lag, dev)
+    gain = gain.detach().to(device=dev, dtype=torch.float32).contiguous().view(-1)
+    B, N = out.shape
+    A, L = dict_unit.shape
+    with torch.cuda.device(dev):
+        rc = lib().mp_scatter_f32(_ptr(atom), _ptr(batch), _ptr(lag), _ptr(gain), atom.numel(),
+                                  _ptr(dict_unit), A, L, _ptr(out), B, N, _stream(out))
+    _check(rc, "mp_scatter_f32")
+    return out
+
+
+def scatter_rows(rows, batch, lag, out):
+    _require_cuda(out, rows)
+    assert out.dtype == torch.float32 and out.is_contiguous() and out.dim() == 2
+    dev = out.device
+    rows = _f32(rows)
+    n, L = rows.shape
+    batch, lag = _i64(batch, dev), _i64(lag, dev)
+    B, N = out.shape
+    with torch.cuda.device(dev):
+        rc = lib().mp_scatter_rows_f32(_ptr(rows), _ptr(batch), _ptr(lag), n, L, _ptr(out), B, N,
+                                       _stream(out))
+    _check(rc, "mp_scatter_rows_f32")
+    return out
+
+
+def gather_sum(x, batch, lag, L):
+    """sum over events of x[batch, lag:lag+L] (zero beyond N) -> float64 [L]."""
+    x = _f32(x)
+    _require_cuda(x)
+    dev = x.device
+    B, N = x.shape
+    batch, lag = _i64(batch, dev), _i64(lag, dev)
+    out = torch.empty((L,), dtype=torch.float64, device=dev)
+    with torch.cuda.device(dev):
+        rc = lib().mp_gather_sum_f32(_ptr(x), B, N, _ptr(batch), _ptr(lag), batch.numel(), L,
+                                     _ptr(out), _stream(x))
+    _check(rc, "mp_gather_sum_f32")
+    return out

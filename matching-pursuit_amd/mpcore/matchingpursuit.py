@@ -1,0 +1,499 @@
+"""Host-side mirror of the reference's `modules.matchingpursuit` surface on top of libmpcore.
+
+Same names, argument meaning, return structures and error behaviour as
+/root/reference/modules/matchingpursuit.py (each function cites the lines it mirrors); the
+arithmetic runs in hand-written HIP kernels through the C ABI (include/mpcore.h).  There is
+no CPU implementation here: tensors that live on the CPU are moved to the current HIP
+device, processed there and the results moved back; without a HIP device every entry point
+raises `NativeError`.
+"""
+from collections import defaultdict
+
+import torch
+from torch import nn
+from torch.nn import functional as F
+
+from . import _native
+from ._native import NativeError
+
+__all__ = [
+    "build_scatter_segments", "flatten_atom_dict", "sparse_code", "dictionary_learning_step",
+    "sparse_feature_map", "sparse_coding_loss", "SparseCodingLoss", "unit_norm", "torch_conv",
+    "fft_convolve", "EventList", "encode_packed",
+]
+
+
+# --------------------------------------------------------------------------------------------
+# device plumbing
+# --------------------------------------------------------------------------------------------
+def _compute_device(t):
+    if t.is_cuda:
+        return t.device
+    if not torch.cuda.is_available():
+        raise NativeError(
+            "mpcore needs a HIP device (MI355X): the input is on the CPU and no GPU is visible; "
+            "there is no CPU fallback")
+    return torch.device("cuda", torch.cuda.current_device())
+
+
+def unit_norm(x, dim=-1, epsilon=1e-8):
+    """modules/normalization.py:4-6.  2-D fp32 along the last axis runs in mp_unit_norm_f32."""
+    if x.dim() == 2 and dim in (-1, 1) and not x.requires_grad:
+        dev = _compute_device(x)
+        return _native.unit_norm(x.to(dev), epsilon).to(x.device)
+    n = torch.norm(x, dim=dim, keepdim=True)
+    return x / (n + epsilon)
+
+
+def torch_conv(signal, atom):
+    """modules/conv.py:4-9: dense feature map [B, A, N] (mp_feature_map_f32)."""
+    n_samples = signal.shape[-1]
+    dev = _compute_device(signal)
+    sig = signal.reshape(-1, n_samples).to(dev)
+    fm = _native.feature_map(sig, atom.to(dev))
+    return fm.to(signal.device)
+
+
+def fft_convolve(signal, atoms, approx=None):
+    """modules/conv.py:11-53.  The exact branch (approx is None, or not a slice / small int,
+    :48-49) is the same map as torch_conv and is served by the direct kernel; the two
+    approximate branches (band slice :24-29, top-k bins :30-47) need the spectra and are
+    restated with torch.fft on the device."""
+    batch = signal.shape[0]
+    n_samples = signal.shape[-1]
+    n_atoms, atom_size = atoms.shape
+    is_slice = isinstance(approx, slice)
+    is_topk = isinstance(approx, int) and not isinstance(approx, bool) and approx < n_samples
+    if not is_slice and not is_topk:
+        return torch_conv(signal, atoms).view(batch, n_atoms, n_samples)
+    dev = _compute_device(signal)
+    sig_t = F.pad(signal.to(dev), (0, atom_size))
+    padded = F.pad(atoms.to(dev), (0, sig_t.shape[-1] - atom_size))
+    sig = torch.fft.rfft(sig_t, dim=-1)
+    atom = torch.fft.rfft(torch.flip(padded, dims=(-1,)), dim=-1)[None, ...]
+    fm_spec = torch.zeros(batch, n_atoms, sig.shape[-1], device=dev, dtype=sig.dtype)
+    if is_slice:
+        fm_spec[..., approx] = sig[..., approx] * atom[..., approx]
+    else:
+        mags = torch.abs(sig)
+        _, indices = torch.topk(mags, k=approx, dim=-1)
+        sig_k = torch.gather(sig, dim=-1, index=indices)
+        atom_k = torch.gather(atom.repeat(batch, 1, 1), dim=-1, index=indices.expand(batch, n_atoms, -1))
+        fm_spec = torch.scatter(fm_spec, dim=-1, index=indices.expand(batch, n_atoms, -1), src=sig_k * atom_k)
+    fm = torch.fft.irfft(fm_spec, dim=-1)
+    fm = torch.roll(fm, 1, dims=(-1,))
+    return fm[..., :n_samples].to(signal.device)
+
+
+# --------------------------------------------------------------------------------------------
+# events
+# --------------------------------------------------------------------------------------------
+class EventList(list):
+    """A list of reference-style event tuples `(atom:int, batch:int, lag:LongTensor[1,1],
+    scaled_atom:FloatTensor[1,1,L])` that also carries the packed device arrays it was built
+    from, so the decoder can run as one kernel instead of a Python loop."""
+    packed = None  # dict(atom, batch, lag, gain: 1-D device tensors, dict_unit: [A, L])
+
+
+def _make_events(atom, lag, gain, dict_unit, out_device):
+    """Packed [B,K] arrays -> (instances dict in first-selection order, flat selection-order
+    EventList).  One host sync (atom.tolist())."""
+    B, K = atom.shape
+    L = dict_unit.shape[1]
+    at_all = (dict_unit[atom] * gain[..., None]).to(out_device)  # d[atom] * value, :305
+    lag_o = lag.to(out_device)
+    atom_l = atom.tolist()
+    instances = defaultdict(list)
+    for i in range(K):            # step-major, batch-minor: the order of :269 / :311
+        for j in range(B):
+            ai = atom_l[j][i]
+            ev = (ai, j, lag_o[j, i].view(1, 1), at_all[j, i].view(1, 1, L))
+            instances[ai].append(ev)
+    return instances, atom_l
+
+
+def encode_packed(signal, d, n_steps, path=None, flags=0):
+    """The fast interface: signal [B,1,N] or [B,N], raw dictionary d [A,L] ->
+    dict(atom[B,K], lag[B,K], gain[B,K], residual[B,N], dict_unit[A,L]) on the compute device,
+    no host synchronisation, no Python objects per event."""
+    if signal.dim() == 3:
+        signal = signal[:, 0, :]
+    dev = _compute_device(signal)
+    du = _native.unit_norm(d.to(dev))
+    p = _native.MP_PATH_INCREMENTAL if path is None else path
+    atom, lag, gain, residual = _native.encode(signal.to(dev), du, n_steps, path=p, flags=flags)
+    return dict(atom=atom, lag=lag, gain=gain, residual=residual, dict_unit=du)
+
+
+# --------------------------------------------------------------------------------------------
+# scatter_segments  (modules/matchingpursuit.py:20-58)
+# --------------------------------------------------------------------------------------------
+def build_scatter_segments(n_samples, atom_size):
+
+    def scatter_segments(x, inst):
+        if isinstance(x, tuple):
+            shape = tuple(x)
+            base = None
+        else:
+            shape = tuple(x.shape)
+            base = x  # the reference concatenates x itself between the pads (:33-34): out = x + events
+        if len(shape) != 3:
+            raise ValueError("scatter_segments expects a (batch, channels, samples) tensor or shape")
+        channels = shape[1] if base is None else 1  # :24-29
+        inst = inst if isinstance(inst, list) else list(inst)
+
+        packed = getattr(inst, "packed", None)
+        needs_grad = any(torch.is_tensor(e[3]) and e[3].requires_grad for e in inst) or (
+            base is not None and base.requires_grad)
+        if channels != 1 or shape[1] != 1 or needs_grad:
+            return _scatter_torch(shape, base, inst, n_samples, atom_size, channels)
+
+        # where the result lives (like the reference: with x, or with the events) and where it is computed
+        if base is not None:
+            ref_t = base
+        elif packed is not None:
+            ref_t = torch.empty(0, device=packed["out_device"])
+        elif len(inst):
+            ref_t = inst[0][3]
+        else:
+            ref_t = torch.empty(0, device="cuda" if torch.cuda.is_available() else "cpu")
+        out_dev = ref_t.device
+        dev = _compute_device(ref_t)
+        B = shape[0]
+        if base is None:
+            out = torch.zeros((B, n_samples), dtype=torch.float32, device=dev)
+        else:
+            out = base.detach().to(dev, torch.float32).reshape(B, n_samples).clone()
+        if len(inst):
+            if packed is not None:
+                _native.scatter(packed["atom"], packed["batch"], packed["lag"], packed["gain"],
+                                packed["dict_unit"], out)
+            else:
+                rows = torch.cat([e[3].reshape(1, atom_size) for e in inst], dim=0).to(dev)
+                batch = torch.tensor([int(e[1]) for e in inst], dtype=torch.int64, device=dev)
+                lag = torch.tensor([int(e[2]) for e in inst], dtype=torch.int64, device=dev)
+                _native.scatter_rows(rows, batch, lag, out)
+        return out.view(B, 1, n_samples).to(out_dev)
+
+    return scatter_segments
+
+
+def _scatter_torch(shape, base, inst, n_samples, atom_size, channels):
+    """Differentiable / multi-channel form of :33-56 in plain torch ops (no kernel needed:
+    these branches are used for small decoder graphs, never in the encode loop)."""
+    if base is None:
+        dev = inst[0][3].device if len(inst) else torch.device("cpu")
+        x = torch.zeros(*shape, device=dev)
+    else:
+        x = base
+    target = torch.cat([torch.zeros_like(x), x, torch.zeros_like(x)], dim=-1)
+    counter = {}
+    for ai, j, p, a in inst:
+        p = int(p)
+        start = n_samples + p
+        end = start + atom_size
+        ch = counter.get(j, 0)
+        if channels == 1:
+            target[j, :, start:end] = target[j, :, start:end] + a.view(-1, atom_size)
+        else:
+            target[j, ch, start:end] = a.view(-1, atom_size)
+        counter[j] = ch + 1
+    return target[..., n_samples:n_samples * 2]
+
+
+def flatten_atom_dict(atom_dict):
+    """modules/matchingpursuit.py:61-65: concatenation of the per-atom lists (grouped by atom
+    in first-selection order, NOT selection order)."""
+    all_instances = EventList()
+    for k, v in atom_dict.items():
+        all_instances.extend(v)
+    return all_instances
+
+
+# --------------------------------------------------------------------------------------------
+# sparse_code  (modules/matchingpursuit.py:229-345)
+# --------------------------------------------------------------------------------------------
+def sparse_code(
+        signal,
+        d,
+        n_steps=100,
+        device=None,
+        approx=None,
+        flatten=False,
+        extract_atom_embedding=None,
+        visit_key_point=None,
+        return_residual=False,
+        local_contrast_norm=False,
+        return_sparse_feature_map=False,
+        compute_feature_map=None,
+        fft_convolution=False):
+    batch, channels, time = signal.shape  # ValueError for non-3-D input, like :244
+    if channels != 1 or d.dim() != 2:
+        raise NotImplementedError("mpcore.sparse_code supports mono signals and [A, L] dictionaries")
+    signal = signal.view(signal.shape[0], channels, -1)
+    n_samples = signal.shape[-1]
+    n_atoms, atom_size = d.shape[0], d.shape[-1]
+    out_dev = signal.device
+    dev = _compute_device(signal)
+
+    d_unit = _native.unit_norm(d.to(dev))  # :254
+    scatter_segments = build_scatter_segments(n_samples, atom_size)  # :259
+
+    approximate = isinstance(approx, slice) or (
+        isinstance(approx, int) and not isinstance(approx, bool) and approx < n_samples)
+    dense = (compute_feature_map is not None or extract_atom_embedding is not None or
+             visit_key_point is not None or local_contrast_norm or approximate)
+
+    if dense:
+        atom, lag, gain, residual, embeddings = _sparse_code_dense(
+            signal.to(dev), d_unit, n_steps, approx if approximate else None, extract_atom_embedding,
+            visit_key_point, local_contrast_norm, compute_feature_map)
+    else:
+        atom, lag, gain, residual = _native.encode(signal.to(dev)[:, 0, :], d_unit, n_steps,
+                                                   path=_native.MP_PATH_INCREMENTAL)
+        embeddings = None
+
+    if extract_atom_embedding is not None:  # :332-333
+        return embeddings, residual.view(batch, 1, n_samples).to(out_dev)
+
+    instances, atom_l = _make_events(atom, lag, gain, d_unit, out_dev)
+
+    if not flatten:  # :335-336
+        return instances, scatter_segments
+
+    flattened = flatten_atom_dict(instances)
+    # packed arrays in the flattened (grouped-by-atom) order, so scatter(shape, events) is one kernel
+    if len(flattened):
+        B, K = atom.shape
+        step_of = {}
+        order = []
+        # flattened order = for each atom key (first-selection order): its events in (step, batch) order
+        for i in range(K):
+            for j in range(B):
+                step_of.setdefault(atom_l[j][i], []).append(j * K + i)
+        for key in instances.keys():
+            order.extend(step_of[key])
+        idx = torch.tensor(order, dtype=torch.int64, device=dev)
+        flattened.packed = dict(atom=atom.reshape(-1)[idx], batch=idx // K, lag=lag.reshape(-1)[idx],
+                                gain=gain.reshape(-1)[idx], dict_unit=d_unit, out_device=out_dev)
+
+    if return_residual:  # :337-339
+        return flattened, scatter_segments, residual.view(batch, 1, n_samples).to(out_dev)
+    if return_sparse_feature_map:  # :340-342, sfm[j, ai, p] += value (:317-318)
+        sfm = torch.zeros(batch, n_atoms, n_samples, device=dev)
+        bidx = torch.arange(batch, device=dev)[:, None].expand_as(atom)
+        sfm.index_put_((bidx.reshape(-1), atom.reshape(-1), lag.reshape(-1)), gain.reshape(-1), accumulate=True)
+        return flattened, scatter_segments, sfm.to(out_dev)
+    return flattened, scatter_segments  # :343-345
+
+
+def _sparse_code_dense(signal, d_unit, n_steps, approx, extract_atom_embedding, visit_key_point,
+                       local_contrast_norm, compute_feature_map):
+    """The hook-serving loop (:269-328): the dense map is materialised every step by
+    mp_feature_map_f32 (or by the caller's compute_feature_map), so this costs A*N*4 bytes per
+    segment per step -- correctness over speed, exactly as the reference does it."""
+    B, _, N = signal.shape
+    A, L = d_unit.shape
+    dev = signal.device
+    residual = signal[:, 0, :].to(torch.float32).clone()
+    atoms, lags, gains, embeddings = [], [], [], []
+    for _ in range(n_steps):
+        if compute_feature_map is not None:
+            fm = compute_feature_map(residual.view(B, 1, N), d_unit)  # :272-273
+        elif approx is None:
+            fm = _native.feature_map(residual, d_unit)  # :275-277
+        else:
+            fm = fft_convolve(residual.view(B, 1, N), d_unit, approx=approx)  # :280
+        if extract_atom_embedding is not None:
+            embeddings.append(extract_atom_embedding(fm, d_unit))  # :282-283
+        if local_contrast_norm:  # :286-296
+            feature_map = fm.view(B, 1, A, N)
+            averages = F.avg_pool2d(feature_map, (9, 9), (1, 1), (4, 4))
+            feature_map = (feature_map - averages).reshape(B, -1)
+            fm = fm.reshape(B, -1)
+            _, mx = torch.max(feature_map, dim=-1, keepdim=True)
+            value = torch.gather(fm, dim=-1, index=mx)
+        else:
+            fm = fm.reshape(B, -1)
+            value, mx = torch.max(fm, dim=-1, keepdim=True)  # :298-299
+        atom_index = mx // N  # :302
+        position = mx % N  # :303
+        if visit_key_point is not None:  # :323-324
+            at = d_unit[atom_index[:, 0]] * value
+            for j in range(B):
+                visit_key_point(fm[j].view(A, N), int(atom_index[j]), position[j].view(1), at[j].view(L))
+        # residual -= scatter(d[atom] * value), cropped at N  (:305, :326-328)
+        _native.scatter(atom_index[:, 0], torch.arange(B, device=dev), position[:, 0], -value[:, 0], d_unit,
+                        residual)
+        atoms.append(atom_index)
+        lags.append(position)
+        gains.append(value)
+    if n_steps == 0:
+        z = torch.zeros((B, 0), device=dev)
+        return z.long(), z.long(), z.float(), residual, embeddings
+    return torch.cat(atoms, 1), torch.cat(lags, 1), torch.cat(gains, 1).float(), residual, embeddings
+
+
+# --------------------------------------------------------------------------------------------
+# dictionary_learning_step  (modules/matchingpursuit.py:348-419)
+# --------------------------------------------------------------------------------------------
+def dictionary_learning_step(
+        signal,
+        d,
+        n_steps=100,
+        device=None,
+        approx=None,
+        local_constrast_norm=False,
+        compute_feature_map=None,
+        fft_convolution=False,
+        process_group=None):
+    """Returns the updated, unit-normed dictionary; `d` itself is not modified (:365).
+
+    `process_group` (extension): when given, `signal` is this rank's shard of a larger batch
+    split contiguously over the group's ranks; the per-atom window sums (the only cross-segment
+    quantity, :400-401) are all-reduced, and every rank returns the same dictionary as a
+    single-device run over the concatenated batch.
+    """
+    batch, channels, time = signal.shape
+    if channels != 1 or d.dim() != 2:
+        raise NotImplementedError("mpcore.dictionary_learning_step supports mono signals and [A, L] dictionaries")
+    n_samples = time
+    n_atoms, atom_size = d.shape
+    out_dev = d.device
+    dev = _compute_device(signal)
+    sig = signal.detach().to(dev, torch.float32).reshape(batch, n_samples)
+
+    d_work = _native.unit_norm(d.detach().to(dev))  # :365 (a new tensor)
+    residual = sig.clone()  # :367 -- the ORIGINAL signal, as in the reference
+
+    dense = compute_feature_map is not None or local_constrast_norm or isinstance(approx, slice) or (
+        isinstance(approx, int) and not isinstance(approx, bool) and approx < n_samples)
+    if dense:
+        atom, lag, gain, _, _ = _sparse_code_dense(sig.view(batch, 1, n_samples), d_work, n_steps,
+                                                   approx if not (approx is None) else None, None, None,
+                                                   local_constrast_norm, compute_feature_map)
+    else:
+        atom, lag, gain, _ = _native.encode(sig, d_work, n_steps, want_residual=False)
+
+    K = atom.shape[1]
+    # per-event payloads as materialised at encode time: a = d[atom] * value (:305), ||a|| (:410)
+    rows = d_work[atom] * gain[..., None]  # [B, K, L]
+    anorm = torch.norm(rows, dim=-1)  # [B, K]
+
+    # global (step-major, batch-minor) first-selection order of atoms (:391, dict insertion order)
+    from . import dist as _dist
+    atom_global, batch_offset = _dist.gather_batch(atom, process_group)
+    atom_host = atom_global.cpu()
+    order = []
+    seen = set()
+    for a in atom_host.t().reshape(-1).tolist():  # transpose: steps outer, batch inner
+        if a not in seen:
+            seen.add(a)
+            order.append(a)
+
+    # local events sorted by (rank of atom in `order`, step, batch): one contiguous slice per atom
+    rank_of = torch.full((n_atoms,), len(order), dtype=torch.int64)
+    rank_of[torch.tensor(order, dtype=torch.int64)] = torch.arange(len(order))
+    local_atom = atom.cpu()
+    step_idx = torch.arange(K)[None, :].expand(batch, K)
+    batch_idx = torch.arange(batch)[:, None].expand(batch, K)
+    sort_key = (rank_of[local_atom] * K + step_idx) * max(batch, 1) + batch_idx
+    perm = torch.argsort(sort_key.reshape(-1))
+    counts = torch.bincount(rank_of[local_atom].reshape(-1), minlength=len(order) + 1).tolist()
+    perm_d = perm.to(dev)
+    ev_batch = batch_idx.reshape(-1).to(dev)[perm_d]
+    ev_lag = lag.reshape(-1)[perm_d]
+    ev_rows = rows.reshape(-1, atom_size)[perm_d]
+    ev_norm = anorm.reshape(-1)[perm_d]
+
+    sparse = torch.empty_like(residual)
+    start = 0
+    for oi, index in enumerate(order):
+        n = counts[oi]
+        sl = slice(start, start + n)
+        start += n
+        if n:
+            sparse.zero_()
+            _native.scatter_rows(ev_rows[sl], ev_batch[sl], ev_lag[sl], sparse)  # :395
+            residual += sparse  # :396
+            acc = _native.gather_sum(residual, ev_batch[sl], ev_lag[sl], atom_size)  # :400-401
+        else:
+            acc = torch.zeros(atom_size, dtype=torch.float64, device=dev)
+        acc = _dist.all_reduce_sum(acc, process_group)
+        new_atom = _native.unit_norm(acc.to(torch.float32).view(1, atom_size))  # :403-404
+        d_work[index] = new_atom[0]  # :406
+        if n:
+            sparse.zero_()
+            _native.scatter_rows(new_atom * ev_norm[sl, None], ev_batch[sl], ev_lag[sl], sparse)  # :408-414
+            residual -= sparse  # :415
+    return _native.unit_norm(d_work).to(out_dev)  # :417-419
+
+
+# --------------------------------------------------------------------------------------------
+# sparse_feature_map / sparse_coding_loss  (modules/matchingpursuit.py:68-146, 422-463)
+# --------------------------------------------------------------------------------------------
+def sparse_feature_map(signal, d, n_steps=100, device=None, approx=None, pooling=None,
+                       return_residual=False):
+    """Forward values of :68-125: the dense [B, A, N] map holding, per step, the feature-map
+    value at that step's argmax (soft_dirac's forward is the one-hot of the argmax, :100-101).
+    Built from the encoder's events; no softmax over A*N per step."""
+    signal = signal.view(signal.shape[0], 1, -1)
+    batch, _, n_samples = signal.shape
+    n_atoms, atom_size = d.shape
+    out_dev = signal.device
+    dev = _compute_device(signal)
+    if signal.requires_grad:
+        raise NotImplementedError(
+            "mpcore.sparse_feature_map: gradients w.r.t. the signal are not implemented yet")
+    d_unit = _native.unit_norm(d.detach().to(dev))
+    approximate = isinstance(approx, slice) or (
+        isinstance(approx, int) and not isinstance(approx, bool) and approx < n_samples)
+    if approximate:
+        atom, lag, gain, residual, _ = _sparse_code_dense(signal.to(dev), d_unit, n_steps, approx, None, None,
+                                                          False, None)
+    else:
+        atom, lag, gain, residual = _native.encode(signal.to(dev)[:, 0, :], d_unit, n_steps)
+    fm = torch.zeros(batch, n_atoms, n_samples, device=dev)
+    if n_steps > 0:
+        bidx = torch.arange(batch, device=dev)[:, None].expand_as(atom)
+        fm.index_put_((bidx.reshape(-1), atom.reshape(-1), lag.reshape(-1)), gain.reshape(-1), accumulate=True)
+    fm = fm.to(out_dev)
+    if return_residual:
+        return fm, residual.view(batch, 1, n_samples).to(out_dev)
+    return fm
+
+
+def sparse_coding_loss(recon, target, d, n_steps=100, device=None, approx=None, pooling=None):
+    """modules/matchingpursuit.py:128-146."""
+    r_map = sparse_feature_map(recon, d, n_steps, device=device, pooling=pooling)
+    with torch.no_grad():
+        t_map = sparse_feature_map(target, d, n_steps, device=device, pooling=pooling)
+    mx = max(r_map.max().item(), t_map.max().item())
+    r_map = r_map / mx
+    t_map = t_map / mx
+    return F.binary_cross_entropy(r_map, t_map)
+
+
+class SparseCodingLoss(nn.Module):
+    """modules/matchingpursuit.py:422-463."""
+
+    def __init__(self, n_atoms, atom_size, n_steps, approx, learning_steps, device=None, pooling=None):
+        super().__init__()
+        self.approx = approx
+        self.n_steps = n_steps
+        self.learning_steps = learning_steps
+        self._steps_executed = 0
+        self.d = unit_norm(torch.zeros(n_atoms, atom_size, device=device).uniform_(-1, 1))
+        self.pooling = pooling
+
+    def _learning_step(self, signal):
+        with torch.no_grad():
+            self.d[:] = dictionary_learning_step(
+                signal, self.d, n_steps=self.n_steps, device=signal.device, approx=self.approx).to(self.d.device)
+            self._steps_executed += 1
+
+    def loss(self, recon, target):
+        if self._steps_executed < self.learning_steps:
+            self._learning_step(target)
+        return sparse_coding_loss(recon, target, self.d, n_steps=self.n_steps, device=recon.device,
+                                  pooling=self.pooling)

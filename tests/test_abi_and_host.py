@@ -1,0 +1,115 @@
+"""CPU-side checks: the C-ABI library loads and exports every symbol include/mpcore.h declares
+(no compute calls without a GPU), the host-side mirror fails loudly without a device, and the
+pure-host pieces (iterative_loss mirror, sharding helpers) agree with the reference's golden
+vectors."""
+import ctypes
+import inspect
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from mpcore import _native as nat
+from mpcore import dist as mpdist
+from mpcore import iterative as mpit
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared_symbols():
+    hdr = open(os.path.join(REPO, "include", "mpcore.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    return sorted(set(re.findall(r"\b(mp_[a-z0-9_]+)\s*\(", hdr)))
+
+
+def test_library_exports_every_declared_symbol():
+    if not os.path.exists(nat.LIB_PATH):
+        import __graft_entry__ as ge
+        ge.build()
+    lib = ctypes.CDLL(nat.LIB_PATH)
+    declared = _declared_symbols()
+    assert len(declared) >= 9
+    for name in declared:
+        assert hasattr(lib, name), f"{name} declared in include/mpcore.h but not exported"
+    assert set(nat.EXPORTS) == set(declared)
+    assert nat.lib().mp_version() >= 1
+
+
+def test_workspace_query_is_host_only_and_validates():
+    n = nat.workspace_bytes(64, 32768, 512, 512, 64, nat.MP_PATH_INCREMENTAL)
+    assert 8 * 2**20 < n < 64 * 2**20  # residual 8.5 MiB + dictionary image 1 MiB + keys
+    with pytest.raises(nat.NativeError):
+        nat.workspace_bytes(1, 1 << 20, 1 << 14, 64, 1, 0)  # A*N >= 2^32
+
+
+@pytest.mark.skipif(torch.cuda.is_available(), reason="checks the no-GPU failure mode")
+def test_product_path_fails_loudly_without_a_gpu():
+    import modules.matchingpursuit as mp
+    with pytest.raises(nat.NativeError):
+        mp.sparse_code(torch.zeros(1, 1, 256), torch.rand(4, 16), n_steps=2)
+    with pytest.raises(nat.NativeError):
+        mp.dictionary_learning_step(torch.zeros(1, 1, 256), torch.rand(4, 16), n_steps=2)
+    with pytest.raises(nat.NativeError):
+        nat.encode(torch.zeros(1, 256), torch.rand(4, 16), 2)
+    with pytest.raises(ValueError):
+        mp.sparse_code(torch.zeros(1, 256), torch.rand(4, 16), n_steps=2)  # non 3-D, like :244
+
+
+def test_drop_in_surface_names():
+    import modules
+    import modules.iterative as it
+    import modules.matchingpursuit as mp
+    for n in ("sparse_code", "dictionary_learning_step", "sparse_feature_map", "build_scatter_segments",
+              "flatten_atom_dict", "sparse_coding_loss", "SparseCodingLoss"):
+        assert hasattr(mp, n)
+    assert hasattr(it, "iterative_loss") and hasattr(it, "sort_channels_descending_norm")
+    assert hasattr(modules, "iterative_loss") and hasattr(modules, "fft_convolve")
+    sig = inspect.signature(mp.sparse_code)
+    assert list(sig.parameters)[:5] == ["signal", "d", "n_steps", "device", "approx"]
+    assert sig.parameters["n_steps"].default == 100
+    assert "local_constrast_norm" in inspect.signature(mp.dictionary_learning_step).parameters  # sic
+
+
+def _stft(x, ws=512, step=128):
+    # same transform the fixture was generated with (stft(x, 512, 128, pad=True))
+    frames = x.shape[-1] // step
+    x = torch.nn.functional.pad(x, (0, ws)).unfold(-1, ws, step)
+    x = x * torch.hann_window(ws)[None, None, :]
+    return torch.abs(torch.fft.rfft(x, norm="ortho"))[:, :, :frames, :]
+
+
+def test_iterative_loss_matches_reference_golden(golden_dir):
+    z = np.load(os.path.join(golden_dir, "iterative_loss.npz"))
+    target = torch.from_numpy(z["target"])
+    chans = torch.from_numpy(z["channels"])
+    assert np.abs(_stft(target).numpy() - z["stft_target"]).max() <= 1e-5
+    for tag, kw in [("default", {}), ("ratio", {"ratio_loss": True}), ("nosort", {"sort_channels": False})]:
+        r, l = mpit.iterative_loss(target, chans, _stft, return_residual=True, **kw)
+        assert r.shape == z[f"residual_{tag}"].shape
+        assert np.abs(r.numpy() - z[f"residual_{tag}"]).max() <= 2e-5
+        assert abs(l.item() - float(z[f"loss_{tag}"])) <= 1e-5 * abs(float(z[f"loss_{tag}"])) + 1e-3
+    srt = mpit.sort_channels_descending_norm(chans)
+    assert np.array_equal(srt.numpy(), z["sorted_channels"])
+    # shape contract of the reference's own test (modules/test_modules.py:41-55)
+    r, _ = mpit.iterative_loss(torch.zeros(3, 1, 2048), torch.zeros(3, 4, 2048), _stft, return_residual=True)
+    assert r.shape == (3, int(np.prod(_stft(torch.zeros(3, 1, 2048)).shape[1:])))
+
+
+def test_iterative_loss_gradients_flow():
+    target = torch.randn(2, 1, 1024)
+    chans = torch.randn(2, 3, 1024, requires_grad=True)
+    loss = mpit.iterative_loss(target, chans, _stft)
+    loss.backward()
+    assert chans.grad is not None and torch.isfinite(chans.grad).all() and chans.grad.abs().sum() > 0
+
+
+def test_shard_range_partitions():
+    for n in (0, 1, 7, 64, 513):
+        for w in (1, 2, 3, 8):
+            spans = [mpdist.shard_range(n, r, w) for r in range(w)]
+            assert spans[0][0] == 0 and spans[-1][1] == n
+            assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+            sizes = [b - a for a, b in spans]
+            assert max(sizes) - min(sizes) <= 1

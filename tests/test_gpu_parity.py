@@ -1,0 +1,225 @@
+"""GPU parity: the HIP path (through the C ABI) against the CPU oracle and the golden vectors.
+
+Bars (BASELINE.json north_star): (atom, lag) bit-exact; gains and residual within 1e-5
+relative fp32.  Against the oracle the HIP kernels are in fact held to BITWISE equality of
+gains and residuals too: v_mfma_f32_32x32x2_f32 is an ascending-k fmaf chain, which is what
+oracle/mp_oracle.c computes.
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from mpcore import _native as nat
+from mpcore import synth
+
+pytestmark = pytest.mark.gpu
+
+REL = 1e-5
+DEV = "cuda:0"
+
+PATHS = [
+    ("naive", nat.MP_PATH_NAIVE, 0),
+    ("direct", nat.MP_PATH_DIRECT, 0),
+    ("direct_nodma", nat.MP_PATH_DIRECT, nat.MP_FLAG_NO_DMA),
+    ("direct_ta32", nat.MP_PATH_DIRECT, nat.MP_FLAG_TA32),
+    ("incremental", nat.MP_PATH_INCREMENTAL, 0),
+    ("incremental_ta32_nodma", nat.MP_PATH_INCREMENTAL, nat.MP_FLAG_TA32 | nat.MP_FLAG_NO_DMA),
+]
+
+# name: (A, L, N, B, K, n_events, seed)
+SHAPES = {
+    "c1": (16, 256, 8192, 1, 8, 6, 11),          # BASELINE configs[0]
+    "ragged": (24, 100, 1000, 2, 12, 8, 12),     # nothing a multiple of anything
+    "mid": (64, 128, 4096, 3, 16, 12, 13),
+    "tiny": (3, 5, 17, 2, 4, 2, 14),
+    "atom_longer_than_segment": (5, 64, 50, 2, 3, 2, 15),
+    "k_chunks": (40, 1100, 3000, 2, 6, 4, 16),   # L > 512: several LDS chunks per correlation
+    "many_atoms": (200, 32, 700, 1, 10, 6, 17),  # A not a multiple of the 64-atom tile
+}
+
+
+def _inputs(shape_name):
+    A, L, N, B, K, n_ev, seed = SHAPES[shape_name]
+    d = synth.make_dictionary(A, L, seed=seed)
+    x = synth.make_segments(B, N, d, n_events=n_ev, seed=seed)
+    return d, x, K
+
+
+def _gpu_encode(x, du, K, path, flags):
+    out = nat.encode(torch.from_numpy(x).to(DEV), torch.from_numpy(du).to(DEV), K, path=path, flags=flags)
+    torch.cuda.synchronize()
+    return [t.cpu().numpy() for t in out]
+
+
+def test_library_loaded_and_device():
+    assert nat.lib().mp_version() >= 1
+    assert torch.cuda.is_available()
+    assert "gfx950" in torch.cuda.get_device_properties(0).gcnArchName
+
+
+@pytest.mark.parametrize("shape", ["c1", "ragged", "tiny", "k_chunks"])
+def test_unit_norm_bitwise(oracle, shape):
+    d, _, _ = _inputs(shape)
+    got = nat.unit_norm(torch.from_numpy(d).to(DEV)).cpu().numpy()
+    assert np.array_equal(got, oracle.unit_norm(d))
+
+
+@pytest.mark.parametrize("shape", ["ragged", "tiny", "atom_longer_than_segment", "k_chunks", "many_atoms", "mid"])
+def test_feature_map_bitwise(oracle, shape):
+    d, x, _ = _inputs(shape)
+    du = oracle.unit_norm(d)
+    got = nat.feature_map(torch.from_numpy(x).to(DEV), torch.from_numpy(du).to(DEV)).cpu().numpy()
+    want = oracle.feature_map(x, du)
+    assert got.shape == want.shape
+    assert np.array_equal(got, want), f"max |diff| = {np.abs(got - want).max()}"
+
+
+@pytest.mark.parametrize("pname,path,flags", PATHS)
+@pytest.mark.parametrize("shape", list(SHAPES))
+def test_encode_bitwise_vs_oracle(oracle, shape, pname, path, flags):
+    d, x, K = _inputs(shape)
+    du = oracle.unit_norm(d)
+    want = oracle.encode(x, du, K)
+    atom, lag, gain, residual = _gpu_encode(x, du, K, path, flags)
+    assert np.array_equal(atom, want["atom"]), (atom, want["atom"])
+    assert np.array_equal(lag, want["lag"]), (lag, want["lag"])
+    assert np.array_equal(gain, want["gain"])
+    assert np.array_equal(residual, want["residual"])
+
+
+@pytest.mark.parametrize("name", ["encode_c1_16x256_n8192_b1_k8", "encode_mid_64x128_n4096_b3_k16",
+                                  "encode_ragged_24x100_n1000_b2_k12",
+                                  "encode_c2shape_512x512_n32768_b2_k12"])
+def test_encode_matches_reference_golden(golden_dir, name):
+    """Against vectors produced by the real reference (tests/golden/generate_golden.py)."""
+    z = np.load(os.path.join(golden_dir, name + ".npz"))
+    if "d_raw" in z.files:
+        d_raw = z["d_raw"]
+    else:
+        A, L = z["d_unit"].shape
+        d_raw = synth.make_dictionary(A, L, seed=int(z["seed"]))
+    K = z["atom"].shape[1]
+    du = nat.unit_norm(torch.from_numpy(d_raw).to(DEV))
+    assert np.abs(du.cpu().numpy() - z["d_unit"]).max() <= 2e-7
+    atom, lag, gain, residual = [t.cpu().numpy() for t in
+                                 nat.encode(torch.from_numpy(z["signal"]).to(DEV), du, K)]
+    gap = (z["top2"][..., 0] - z["top2"][..., 1]) / np.abs(z["top2"][..., 0])
+    assert gap.min() >= 1e-4
+    assert np.array_equal(atom, z["atom"]) and np.array_equal(lag, z["lag"])
+    assert np.abs(gain - z["gain"]).max() <= REL * np.abs(z["gain"]).max()
+    assert np.abs(residual - z["residual"]).max() <= REL * np.abs(z["signal"]).max()
+    rdb = 20 * np.log10(np.linalg.norm(residual, axis=-1) / np.linalg.norm(z["signal"], axis=-1))
+    assert np.abs(rdb - z["residual_db"]).max() <= 1e-3
+
+
+def test_scatter_decoder_vs_oracle_and_golden(oracle, golden_dir):
+    z = np.load(os.path.join(golden_dir, "primitives.npz"))
+    du = oracle.unit_norm(z["d_raw"])
+    out = torch.zeros(2, 300, device=DEV)
+    nat.scatter(torch.from_numpy(z["ev_atom"]), torch.from_numpy(z["ev_batch"]), torch.from_numpy(z["ev_lag"]),
+                torch.from_numpy(z["ev_gain"]), torch.from_numpy(du).to(DEV), out)
+    want = oracle.scatter(z["ev_atom"], z["ev_batch"], z["ev_lag"], z["ev_gain"], du, 2, 300)
+    assert np.array_equal(out.cpu().numpy(), want)
+    assert np.abs(out.cpu().numpy() - z["decoded"][:, 0, :]).max() <= 1e-6
+    # explicit rows, overlapping events in one segment, negative and cropped lags
+    rows = np.arange(4 * 8, dtype=np.float32).reshape(4, 8) / 7
+    batch = np.array([0, 0, 1, 0])
+    lag = np.array([3, 5, 296, -2])
+    out = torch.zeros(2, 300, device=DEV)
+    nat.scatter_rows(torch.from_numpy(rows).to(DEV), torch.from_numpy(batch), torch.from_numpy(lag), out)
+    assert np.array_equal(out.cpu().numpy(), oracle.scatter_rows(rows, batch, lag, 2, 300))
+
+
+def test_encode_is_deterministic_and_async_safe():
+    d, x, K = _inputs("mid")
+    du = nat.unit_norm(torch.from_numpy(d).to(DEV))
+    xs = torch.from_numpy(x).to(DEV)
+    a = [t.clone() for t in nat.encode(xs, du, K)]
+    b = [t.clone() for t in nat.encode(xs, du, K)]
+    torch.cuda.synchronize()
+    for p, q in zip(a, b):
+        assert torch.equal(p, q)
+
+
+def test_empty_batch_and_zero_steps():
+    du = nat.unit_norm(torch.rand(8, 16, device=DEV))
+    atom, lag, gain, res = nat.encode(torch.zeros(0, 64, device=DEV), du, 4)
+    assert atom.shape == (0, 4) and res.shape == (0, 64)
+    x = torch.rand(2, 64, device=DEV)
+    atom, lag, gain, res = nat.encode(x, du, 0)
+    assert atom.shape == (2, 0) and torch.equal(res, x)
+
+
+def test_all_zero_signal_picks_index_zero(oracle):
+    du = oracle.unit_norm(synth.make_dictionary(8, 16, seed=3))
+    x = np.zeros((1, 100), dtype=np.float32)
+    want = oracle.encode(x, du, 2)
+    atom, lag, gain, res = _gpu_encode(x, du, 2, nat.MP_PATH_INCREMENTAL, 0)
+    assert np.array_equal(atom, want["atom"]) and np.array_equal(lag, want["lag"])
+    assert (atom == 0).all() and (lag == 0).all() and (gain == 0).all()
+
+
+def test_bad_arguments_fail_loudly():
+    du = torch.rand(8, 16, device=DEV)
+    with pytest.raises(nat.NativeError):
+        nat.encode(torch.zeros(1, 64), du, 1)  # CPU tensor
+    with pytest.raises(nat.NativeError):
+        nat.encode(torch.zeros(1, 64, device=DEV), du, 1, path=nat.MP_PATH_FFT)
+    with pytest.raises(nat.NativeError):
+        nat.encode(torch.zeros(1, 64, device=DEV), du, 1, path=77)
+
+
+# ---- BASELINE.json configs[1] shape: properties that do not need the (slow) oracle ---------------
+@pytest.fixture(scope="module")
+def c2_inputs():
+    d = synth.make_dictionary(512, 512, seed=2)
+    x = synth.make_segments(16, 32768, d, n_events=96, seed=2)
+    return torch.from_numpy(d).to(DEV), torch.from_numpy(x).to(DEV)
+
+
+def test_c2_incremental_equals_direct_bitwise(c2_inputs):
+    d, x = c2_inputs
+    du = nat.unit_norm(d)
+    K = 24
+    inc = nat.encode(x, du, K, path=nat.MP_PATH_INCREMENTAL)
+    full = nat.encode(x, du, K, path=nat.MP_PATH_DIRECT)
+    ta32 = nat.encode(x, du, K, path=nat.MP_PATH_INCREMENTAL, flags=nat.MP_FLAG_TA32)
+    torch.cuda.synchronize()
+    for p, q, r in zip(inc, full, ta32):
+        assert torch.equal(p, q) and torch.equal(p, r)
+
+
+def test_c2_roundtrip_and_monotone_energy(c2_inputs):
+    d, x = c2_inputs
+    du = nat.unit_norm(d)
+    K = 64
+    atom, lag, gain, residual = nat.encode(x, du, K)
+    B, N = x.shape
+    # decode(events) + residual == signal  (encode -> decode round trip)
+    recon = torch.zeros_like(x)
+    batch = torch.arange(B, device=DEV)[:, None].expand(B, K)
+    nat.scatter(atom, batch, lag, gain, du, recon)
+    err = (recon + residual - x).abs().max().item()
+    assert err <= REL * x.abs().max().item() * 4
+    # every step removes energy: ||r||^2 decreases by ~gain^2 for interior events
+    assert (gain > 0).all()
+    e0 = (x.double() ** 2).sum(-1)
+    e1 = (residual.double() ** 2).sum(-1)
+    assert (e1 < e0).all()
+    interior = lag + du.shape[1] <= N
+    removed = ((gain.double() ** 2) * interior).sum(-1)
+    assert ((e0 - e1) >= 0.99 * removed).all()
+    # the first event of a segment is its largest
+    assert (gain[:, 0:1] >= gain - 1e-6).all()
+
+
+def test_c2_golden_shape_vs_oracle_bitwise(oracle, c2_inputs):
+    d, x = c2_inputs
+    du = nat.unit_norm(d)
+    K = 6
+    atom, lag, gain, residual = [t.cpu().numpy() for t in nat.encode(x[:2], du, K)]
+    want = oracle.encode(x[:2].cpu().numpy(), du.cpu().numpy(), K)
+    assert np.array_equal(atom, want["atom"]) and np.array_equal(lag, want["lag"])
+    assert np.array_equal(gain, want["gain"]) and np.array_equal(residual, want["residual"])
