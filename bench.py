@@ -67,6 +67,23 @@ def timed_encodes(x, du, steps, warmup, path, flags, group):
     return float(t.item()), out, nat.profile_read()
 
 
+def pmc_traffic():
+    """HBM bytes per launch of the correlate kernel from the newest committed PMC summary
+    (profiles/rNN_summary.json: FETCH_SIZE x2 + WRITE_SIZE, separate rocprofv3 --pmc passes of this
+    same command; counters cannot be read from inside the process).  None if there is none."""
+    import glob
+    files = sorted(glob.glob(os.path.join(REPO, "profiles", "r*_summary.json")))
+    for f in reversed(files):
+        try:
+            d = json.load(open(f))
+        except (OSError, ValueError):
+            continue
+        for k, v in d.items():
+            if k.startswith("hbm_traffic_bytes_per_launch_correlate"):
+                return {"bytes_per_launch": v, "source": os.path.relpath(f, REPO)}
+    return None
+
+
 def roofline_from(prof, flops_one_encode, steps):
     ms_full, n_full = prof["corr_full"]
     ms_inc, n_inc = prof["corr_inc"]
@@ -78,8 +95,8 @@ def roofline_from(prof, flops_one_encode, steps):
     achieved = total * steps / sec / 1e12
     return {
         "bound": "mfma", "achieved": round(achieved, 3), "peak": PEAK_MFMA_F32_TFLOPS, "unit": "TFLOP/s",
-        "frac": round(achieved / PEAK_MFMA_F32_TFLOPS, 4), "traffic": None,
-        "kernel": "correlate_mfma_kernel (v_mfma_f32_32x32x2_f32)",
+        "frac": round(achieved / PEAK_MFMA_F32_TFLOPS, 4), "traffic": pmc_traffic(),
+        "kernel": "correlate_persistent_kernel<32,true> (v_mfma_f32_32x32x2_f32)",
         "launches": launches, "avg_launch_ms": round((ms_full + ms_inc) / launches, 5),
         "full_pass_launches": n_full, "full_pass_avg_ms": round(ms_full / max(n_full, 1), 5),
         "incremental_launches": n_inc, "incremental_avg_ms": round(ms_inc / max(n_inc, 1), 5),
@@ -88,19 +105,35 @@ def roofline_from(prof, flops_one_encode, steps):
     }
 
 
+def host_cpu_share():
+    """CPUs this process may actually use: affinity mask, capped by the cgroup CPU quota (the GPU
+    box exposes 256 logical CPUs but grants a 16-CPU share)."""
+    n = len(os.sched_getaffinity(0))
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
 def cpu_baseline(d, x_host, gpu_sample):
     """The oracle (oracle/mp_oracle.c, the CPU restatement of the reference) on this host's cores,
     on a bounded sample of the same workload; also the in-run parity check."""
     sys.path.insert(0, os.path.join(REPO, "oracle"))
     import mp_oracle
     mp_oracle.build()
-    threads = mp_oracle.num_threads()
+    threads = host_cpu_share()
+    mp_oracle.set_num_threads(threads)
     du = mp_oracle.unit_norm(d)
+    mp_oracle.encode(x_host[:1], du, 1)  # warm the thread pool
     t0 = time.perf_counter()
-    mp_oracle.encode(x_host[:1], du, 2)
-    per = (time.perf_counter() - t0) / 2
-    k_s = 8
-    b_s = int(min(max(round(15.0 / (per * k_s)), 1), 16, x_host.shape[0]))
+    mp_oracle.encode(x_host[:2], du, 2)
+    per = (time.perf_counter() - t0) / 4
+    # about 15 s of CPU work: up to 16 segments, then as many iterations as fit (<= K)
+    b_s = int(min(max(round(15.0 / (per * 8)), 1), 16, x_host.shape[0]))
+    k_s = int(min(max(round(15.0 / (per * b_s)), 4), K_ITERS))
     t0 = time.perf_counter()
     want = mp_oracle.encode(x_host[:b_s], du, k_s)
     dt = time.perf_counter() - t0
@@ -113,7 +146,7 @@ def cpu_baseline(d, x_host, gpu_sample):
     }
     return {
         "value": round(b_s * k_s / dt, 3), "unit": "segment-iterations/s", "cores": threads, "kind": "port",
-        "sample": f"{b_s} of the 64 segments x {k_s} iterations (rate is K-independent), "
+        "sample": f"{b_s} of the 64 segments x the first {k_s} of 64 iterations, "
                   f"oracle/mp_oracle.c with OpenMP on {threads} threads, {dt:.1f} s",
     }, parity
 

@@ -43,7 +43,10 @@ extern "C" {
 
 /* mp_encode_f32 `flags` (tuning / A-B switches; results never depend on them) */
 #define MP_FLAG_NO_DMA 1 /* stage the dictionary tile through registers instead of LDS-DMA */
-#define MP_FLAG_TA32 2   /* 32-atom workgroup tiles (64 KiB of LDS, two workgroups per CU)  */
+#define MP_FLAG_TA32 2   /* 32-atom workgroup tiles (64 KiB of LDS, two workgroups per CU): default */
+#define MP_FLAG_TA64 4   /* 64-atom workgroup tiles (128 KiB of LDS, one workgroup per CU)         */
+#define MP_FLAG_NO_STAGGER 16 /* do not delay odd wave slots by half a cell on incremental launches */
+#define MP_FLAG_NO_PERSISTENT 8 /* one workgroup per 4 cells instead of machine-sized persistent grid */
 
 int mp_version(void);
 const char *mp_last_error(void);

@@ -78,7 +78,6 @@ typedef unsigned long long u64;
 
 constexpr int LAGS_PER_WAVE = 64;   // one cell = TA atoms x 64 lags, owned by one wavefront
 constexpr int WAVES = 4;            // wavefronts per workgroup
-constexpr int WG_LAGS = LAGS_PER_WAVE * WAVES;
 constexpr int KC_MAX = 512;         // atom samples staged in LDS per chunk
 
 __host__ __device__ inline int64_t round_up(int64_t x, int64_t m) { return (x + m - 1) / m * m; }
@@ -95,8 +94,7 @@ struct Geom {
     int NCH;       // k chunks
     int Lpp;       // NCH * KC  (dictionary k extent incl. zero padding)
     int64_t Ns;    // residual row stride in floats (zero padded past N)
-    int NGRP_FULL; // workgroups along lags for a full pass
-    int NGRP_INC;  // workgroups along lags for a dirty window
+    int MAXC;      // most 64-lag blocks one subtraction can dirty
 };
 
 Geom make_geom(int64_t B, int64_t N, int64_t A, int64_t L, int TA) {
@@ -108,12 +106,11 @@ Geom make_geom(int64_t B, int64_t N, int64_t A, int64_t L, int TA) {
     g.KC = Lp < KC_MAX ? Lp : KC_MAX;
     g.NCH = (Lp + g.KC - 1) / g.KC;
     g.Lpp = g.NCH * g.KC;
-    g.Ns = round_up((int64_t)g.NBLK * LAGS_PER_WAVE + WG_LAGS + g.Lpp + 64, 64);
-    g.NGRP_FULL = (g.NBLK + WAVES - 1) / WAVES;
+    g.Ns = round_up((int64_t)g.NBLK * LAGS_PER_WAVE + g.Lpp + 64, 64);
     // a subtraction at lag p changes lags [p-L+1, p+L-1]: at most this many 64-lag blocks
     int nb = (int)((2 * L - 2) / LAGS_PER_WAVE) + 2;
     if (nb > g.NBLK) nb = g.NBLK;
-    g.NGRP_INC = (nb + WAVES - 1) / WAVES;
+    g.MAXC = nb;
     return g;
 }
 
@@ -206,94 +203,46 @@ __global__ void copy_residual_kernel(const float *__restrict__ res, int64_t N, i
 }
 
 // ------------------------------------------------------------------------------------------------
-// Correlate: one workgroup = (segment b, atom tile, 4 consecutive 64-lag blocks), one wavefront per
-// block.  GEMM view per wavefront: C[64 lags x TA atoms] = R[64 x L] (Toeplitz: R[t][k] = r[t+k])
-// times D^T[L x TA], on v_mfma_f32_32x32x2_f32 (A operand = residual, B operand = dictionary).
-//   A operand lane map: lane l holds R[row l&31][k l>>5]  -> LDS word  win[t + (l&31) + (l>>5) + k]
-//   B operand lane map: lane l holds D[k l>>5][col l&31]  -> component j of the 16-byte image word
-//   C/D: col = lane & 31 (atom), row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5) (lag)
-// Every product chain is ascending in k: bit-identical to the oracle's fmaf chain.
-// STORE_FM: additionally write the dense map (hooks that need it); keys are still produced.
+// Shared pieces of the correlate kernels
 // ------------------------------------------------------------------------------------------------
-template <int TA, bool STORE_FM, bool DMA>
-__global__ __launch_bounds__(256) void correlate_mfma_kernel(
-    const float *__restrict__ res, const float *__restrict__ img, const int *__restrict__ dirty,
-    u64 *__restrict__ keys, float *__restrict__ fm, int64_t N, int64_t A, int64_t Ns, int NBLK, int NAT,
-    int KC, int NCH) {
-    constexpr int NT = TA / 32;  // 32-atom sub-tiles per wavefront
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    float *img_s = reinterpret_cast<float *>(smem);                 // KC * TA floats
-    float *win_s = img_s + (size_t)KC * TA;                         // KC + WG_LAGS floats
-
-    const int b = blockIdx.z;
-    const int tile = blockIdx.y;
-    int first = 0, count = NBLK;
-    if (dirty) {
-        first = dirty[2 * b];
-        count = dirty[2 * b + 1];
-    }
-    const int grp0 = blockIdx.x * WAVES;  // first block of this workgroup, relative to `first`
-    if (grp0 >= count) return;            // uniform: whole workgroup has nothing to do
-
-    const int tid = threadIdx.x;
-    const int w = tid >> 6;
-    const int lane = tid & 63;
-    const int i = lane & 31;
-    const int h = lane >> 5;
-    const int blk0 = first + grp0;
-    const int64_t tbase = (int64_t)blk0 * LAGS_PER_WAVE;
-    const bool active = (grp0 + w) < count;  // wave-uniform
-
-    f32x16 acc[2][NT];
-#pragma unroll
-    for (int s = 0; s < 2; ++s)
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[s][nt][r] = 0.0f;
-
-    const float *res_b = res + (int64_t)b * Ns;
-    const f32x4 *img_g = reinterpret_cast<const f32x4 *>(img) + (size_t)tile * NCH * (KC * TA / 4);
-
-    for (int c = 0; c < NCH; ++c) {
-        if (c > 0) __syncthreads();  // previous chunk fully consumed
-        // ---- stage the dictionary chunk (already in LDS order) and the residual window ------------
-        {
-            const f32x4 *src = img_g + (size_t)c * (KC * TA / 4);
-            const int n4 = KC * TA / 4;  // multiple of 256: KC % 16 == 0, TA % 32 == 0
-            if (DMA) {
-                // LDS-DMA: each wave-instruction moves 64 x 16 B = 1 KiB, LDS address = wave-uniform
-                // base + lane * 16 (the image is linear in both memories, so no swizzle is needed).
-                for (int e0 = w * 64; e0 < n4; e0 += 256) {
-                    __builtin_amdgcn_global_load_lds(
-                        (const __attribute__((address_space(1))) void *)(src + e0 + lane),
-                        (__attribute__((address_space(3))) void *)(img_s + (size_t)e0 * 4),
-                        16, 0, 0);
-                }
-            } else {
-                f32x4 *dst = reinterpret_cast<f32x4 *>(img_s);
-                for (int e0 = tid; e0 < n4; e0 += 256 * 8) {
-                    f32x4 tmp[8];
-#pragma unroll
-                    for (int u = 0; u < 8; ++u) tmp[u] = src[e0 + u * 256];
-#pragma unroll
-                    for (int u = 0; u < 8; ++u) dst[e0 + u * 256] = tmp[u];
-                }
-            }
-            const f32x4 *wsrc = reinterpret_cast<const f32x4 *>(res_b + tbase + (int64_t)c * KC);
-            f32x4 *wdst = reinterpret_cast<f32x4 *>(win_s);
-            const int w4 = (KC + WG_LAGS) / 4;
-            for (int e = tid; e < w4; e += 256) wdst[e] = wsrc[e];
+// Stage KC x TA floats of dictionary image (already in LDS order) into LDS; all 256 threads call it.
+template <bool DMA>
+__device__ __forceinline__ void stage_image(const f32x4 *__restrict__ src, float *img_s, int n4, int tid) {
+    if (DMA) {
+        // LDS-DMA: each wave-instruction moves 64 x 16 B = 1 KiB, LDS address = wave-uniform base +
+        // lane * 16 (the image is linear in both memories, so no swizzle is needed).
+        const int w = tid >> 6, lane = tid & 63;
+        for (int e0 = w * 64; e0 < n4; e0 += 256) {
+            __builtin_amdgcn_global_load_lds(
+                (const __attribute__((address_space(1))) void *)(src + e0 + lane),
+                (__attribute__((address_space(3))) void *)(img_s + (size_t)e0 * 4), 16, 0, 0);
         }
-        __syncthreads();  // hipcc drains vmcnt(0) here while LDS-DMA is outstanding
-        if (active) {
-            const f32x4 *bp = reinterpret_cast<const f32x4 *>(img_s) + h * TA + i;
-            const float *ap = win_s + w * LAGS_PER_WAVE + i + h;
-            const int ngrp = KC / 8;  // even
-            // software pipeline, two k8-groups per trip: operands of the next group are in flight
-            // while the 8*NT MFMAs (512*NT cycles) of the current one issue.
-            f32x4 bA[NT], bB[NT];
-            float aA[8], aB[8];
+    } else {
+        f32x4 *dst = reinterpret_cast<f32x4 *>(img_s);
+        for (int e0 = tid; e0 < n4; e0 += 256 * 8) {  // n4 is a multiple of 2048 / (512/KC)... see callers
+            f32x4 tmp[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) tmp[u] = (e0 + u * 256 < n4) ? src[e0 + u * 256] : f32x4{0, 0, 0, 0};
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                if (e0 + u * 256 < n4) dst[e0 + u * 256] = tmp[u];
+        }
+    }
+}
+
+// One k-chunk of a cell: acc[s][nt] += R[64 lags x KC] * D^T[KC x 32*NT atoms]  (ascending k).
+// img_s: staged image chunk; win_s: this wave's residual window (win_s[j] = r[t0 + k0 + j]).
+template <int TA>
+__device__ __forceinline__ void mfma_chunk(const float *img_s, const float *win_s, int KC, int i, int h,
+                                           f32x16 (&acc)[2][TA / 32]) {
+    constexpr int NT = TA / 32;
+    const f32x4 *bp = reinterpret_cast<const f32x4 *>(img_s) + h * TA + i;
+    const float *ap = win_s + i + h;
+    const int ngrp = KC / 8;  // even
+    // software pipeline, two k8-groups per trip: operands of the next group are in flight while the
+    // 8*NT MFMAs (512*NT cycles) of the current one issue.
+    f32x4 bA[NT], bB[NT];
+    float aA[8], aB[8];
 #define MP_LOAD_GROUP(BQ, AQ, G)                                                        \
     {                                                                                   \
         _Pragma("unroll") for (int nt = 0; nt < NT; ++nt) BQ[nt] = bp[(size_t)(G) * 2 * TA + nt * 32]; \
@@ -311,60 +260,153 @@ __global__ __launch_bounds__(256) void correlate_mfma_kernel(
             }                                                                           \
         }                                                                               \
     }
-            MP_LOAD_GROUP(bA, aA, 0)
-            for (int g = 0; g < ngrp; g += 2) {
-                MP_LOAD_GROUP(bB, aB, g + 1)
-                MP_MFMA_GROUP(bA, aA)
-                MP_LOAD_GROUP(bA, aA, g + 2)  // last trip reads the LDS pad: loaded, never used
-                MP_MFMA_GROUP(bB, aB)
-                // pin the issue order: a group's LDS reads go out ahead of the PREVIOUS group's
-                // MFMAs, so their latency hides under 8*NT x 64 cycles of matrix work
-                __builtin_amdgcn_sched_group_barrier(0x100, NT + 4, 0);  // DS reads (ds_read2 pairs)
-                __builtin_amdgcn_sched_group_barrier(0x008, 8 * NT, 0);  // MFMA
-                __builtin_amdgcn_sched_group_barrier(0x100, NT + 4, 0);
-                __builtin_amdgcn_sched_group_barrier(0x008, 8 * NT, 0);
-            }
+    MP_LOAD_GROUP(bA, aA, 0)
+    for (int g = 0; g < ngrp; g += 2) {
+        MP_LOAD_GROUP(bB, aB, g + 1)
+        MP_MFMA_GROUP(bA, aA)
+        MP_LOAD_GROUP(bA, aA, g + 2)  // last trip reads the LDS pad: loaded, never used
+        MP_MFMA_GROUP(bB, aB)
+        // pin the issue order: a group's LDS reads go out ahead of the PREVIOUS group's MFMAs, so
+        // their latency hides under 8*NT x 64 cycles of matrix work
+        __builtin_amdgcn_sched_group_barrier(0x100, NT + 4, 0);  // DS reads (ds_read2 pairs)
+        __builtin_amdgcn_sched_group_barrier(0x008, 8 * NT, 0);  // MFMA
+        __builtin_amdgcn_sched_group_barrier(0x100, NT + 4, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 8 * NT, 0);
+    }
 #undef MP_LOAD_GROUP
 #undef MP_MFMA_GROUP
-        }
-    }
-    if (!active) return;
+}
 
-    // ---- epilogue: signed max of the cell, first flat index on ties -------------------------------
-    const int blk = blk0 + w;
-    const int64_t t0 = (int64_t)blk * LAGS_PER_WAVE;
+// Signed maximum of a finished cell with torch.max's tie rule, as a key (wave-uniform result).
+// lane (i, h) holds, for sub-tile (s, nt) and register r:  atom = tile*TA + nt*32 + i,
+// lag = t0 + s*32 + (r&3) + 8*(r>>2) + 4*h.  Invalid lanes/lags are overwritten with -inf in acc.
+template <int TA>
+__device__ __forceinline__ u64 cell_key(f32x16 (&acc)[2][TA / 32], int tile, int64_t t0, int64_t N,
+                                        int64_t A, int i, int h) {
+    constexpr int NT = TA / 32;
+    const bool whole = (t0 + LAGS_PER_WAVE <= N) && ((int64_t)(tile + 1) * TA <= A);  // wave-uniform
+    if (!whole) {
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                const int64_t atom = (int64_t)tile * TA + nt * 32 + i;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int64_t lag = t0 + s * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                    if (!((lag < N) && (atom < A))) acc[s][nt][r] = -INFINITY;
+                }
+            }
+    }
     float m = -INFINITY;
 #pragma unroll
     for (int s = 0; s < 2; ++s)
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt) {
-            const int64_t atom = (int64_t)tile * TA + nt * 32 + i;
+        for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int64_t lag = t0 + s * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-                const bool ok = (lag < N) && (atom < A);
-                float v = ok ? acc[s][nt][r] : -INFINITY;
-                acc[s][nt][r] = v;
-                m = fmaxf(m, v);
-            }
-        }
+            for (int r = 0; r < 16; ++r) m = fmaxf(m, acc[s][nt][r]);
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
+    // lowest flat index holding the wave maximum: walk downwards, last write wins
     unsigned best = 0xffffffffu;
+#pragma unroll
+    for (int nt = NT - 1; nt >= 0; --nt) {
+        const int64_t atom = (int64_t)tile * TA + nt * 32 + i;
+        const unsigned base = (unsigned)(atom * N + t0 + 4 * h);  // < 2^32 whenever atom < A
+        const bool atom_ok = atom < A;
+#pragma unroll
+        for (int s = 1; s >= 0; --s)
+#pragma unroll
+            for (int r = 15; r >= 0; --r) {
+                const int dl = s * 32 + (r & 3) + 8 * (r >> 2);
+                bool hit = acc[s][nt][r] == m;
+                if (!whole) hit = hit && atom_ok && (t0 + dl + 4 * h < N);
+                best = hit ? base + (unsigned)dl : best;
+            }
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        const unsigned o = __shfl_xor(best, off, 64);
+        best = o < best ? o : best;
+    }
+    return best == 0xffffffffu ? 0ull : make_key(m, best);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Correlate: one wavefront = one cell task (segment b, 64-lag block, atom tile); the 4 wavefronts of a
+// workgroup take 4 consecutive tasks of the SAME atom tile (so they share the staged dictionary
+// image) from the flattened list  task = b * stride + c,  c-th block of segment b's dirty run
+// (stride = blocks per segment for a full pass, max dirty blocks for an incremental one); a
+// workgroup may therefore straddle segments, and every wavefront stages its own residual window.
+// GEMM view per wavefront: C[64 lags x TA atoms] = R[64 x L] (Toeplitz: R[t][k] = r[t+k])
+// times D^T[L x TA], on v_mfma_f32_32x32x2_f32 (A operand = residual, B operand = dictionary).
+//   A operand lane map: lane l holds R[row l&31][k l>>5]  -> LDS word  win[(l&31) + (l>>5) + k]
+//   B operand lane map: lane l holds D[k l>>5][col l&31]  -> component j of the 16-byte image word
+//   C/D: col = lane & 31 (atom), row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5) (lag)
+// Every product chain is ascending in k: bit-identical to the oracle's fmaf chain.
+// STORE_FM: additionally write the dense map (hooks that need it); keys are still produced.
+// ------------------------------------------------------------------------------------------------
+template <int TA, bool STORE_FM, bool DMA>
+__global__ __launch_bounds__(256) void correlate_mfma_kernel(
+    const float *__restrict__ res, const float *__restrict__ img, const int *__restrict__ dirty,
+    u64 *__restrict__ keys, float *__restrict__ fm, int64_t N, int64_t A, int64_t Ns, int64_t B, int NBLK,
+    int NAT, int KC, int NCH, int stride) {
+    constexpr int NT = TA / 32;  // 32-atom sub-tiles per wavefront
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float *img_s = reinterpret_cast<float *>(smem);  // KC * TA floats
+    const int WIN = KC + LAGS_PER_WAVE + 16;         // per-wavefront residual window (+ prefetch pad)
+    float *win_all = img_s + (size_t)KC * TA;
+
+    const int tile = blockIdx.y;
+    const int tid = threadIdx.x;
+    const int w = tid >> 6;
+    const int lane = tid & 63;
+    const int i = lane & 31;
+    const int h = lane >> 5;
+
+    // this wavefront's task (everything here is wave-uniform)
+    const int64_t task = (int64_t)blockIdx.x * WAVES + w;
+    const int64_t b = task / stride;
+    const int c = (int)(task - b * stride);
+    int first = 0, count = NBLK;
+    bool active = b < B;
+    if (active && dirty) {
+        first = dirty[2 * b];
+        count = dirty[2 * b + 1];
+    }
+    active = active && (c < count);
+    const int blk = first + c;
+    const int64_t t0 = (int64_t)blk * LAGS_PER_WAVE;
+    float *win_s = win_all + (size_t)w * WIN;
+
+    f32x16 acc[2][NT];
 #pragma unroll
     for (int s = 0; s < 2; ++s)
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt) {
-            const int64_t atom = (int64_t)tile * TA + nt * 32 + i;
+        for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int64_t lag = t0 + s * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-                const unsigned flat = (unsigned)(atom * N + lag);
-                const bool hit = (acc[s][nt][r] == m) && (lag < N) && (atom < A);
-                best = (hit && flat < best) ? flat : best;
-            }
+            for (int r = 0; r < 16; ++r) acc[s][nt][r] = 0.0f;
+
+    const float *res_b = res + (active ? b : 0) * Ns;
+    const f32x4 *img_g = reinterpret_cast<const f32x4 *>(img) + (size_t)tile * NCH * (KC * TA / 4);
+
+    for (int c_k = 0; c_k < NCH; ++c_k) {
+        if (c_k > 0) __syncthreads();  // previous chunk fully consumed
+        // ---- stage the dictionary chunk and this wave's residual window ---------------------------
+        stage_image<DMA>(img_g + (size_t)c_k * (KC * TA / 4), img_s, KC * TA / 4, tid);
+        if (active) {
+            const f32x4 *wsrc = reinterpret_cast<const f32x4 *>(res_b + t0 + (int64_t)c_k * KC);
+            f32x4 *wdst = reinterpret_cast<f32x4 *>(win_s);
+            const int w4 = (KC + LAGS_PER_WAVE) / 4;
+            for (int e = lane; e < w4; e += 64) wdst[e] = wsrc[e];
         }
-    u64 key = best == 0xffffffffu ? 0ull : make_key(m, best);
-    key = wave_max_u64(key);
-    if (lane == 0) keys[((int64_t)b * NBLK + blk) * NAT + tile] = key;
+        __syncthreads();  // hipcc drains vmcnt(0) here while LDS-DMA is outstanding
+        if (active) mfma_chunk<TA>(img_s, win_s, KC, i, h, acc);
+    }
+    if (!active) return;
+
+    const u64 key = cell_key<TA>(acc, tile, t0, N, A, i, h);
+    if (lane == 0) keys[(b * NBLK + blk) * NAT + tile] = key;
 
     if (STORE_FM) {
 #pragma unroll
@@ -373,7 +415,7 @@ __global__ __launch_bounds__(256) void correlate_mfma_kernel(
             for (int nt = 0; nt < NT; ++nt) {
                 const int64_t atom = (int64_t)tile * TA + nt * 32 + i;
                 if (atom < A) {
-                    float *row = fm + ((int64_t)b * A + atom) * N;
+                    float *row = fm + (b * A + atom) * N;
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
                         const int64_t lag = t0 + s * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
@@ -381,6 +423,122 @@ __global__ __launch_bounds__(256) void correlate_mfma_kernel(
                     }
                 }
             }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Persistent correlate (atoms of at most KC_MAX samples, i.e. one k-chunk): the grid is sized to the
+// machine (WGS_PER_CU workgroups per CU) instead of to the problem.  The flattened task list
+//   task = tile * LT + lagtask,   lagtask = b * stride + c   (LT = B * stride)
+// is cut into equal contiguous ranges, one per workgroup.  A workgroup stages the dictionary image
+// of a tile ONCE and its four wavefronts then pull that range's cell tasks from an LDS counter, so a
+// wavefront never waits for another between cells and staging is amortised over many cells.
+// ------------------------------------------------------------------------------------------------
+template <int TA, bool DMA>
+__global__ __launch_bounds__(256) void correlate_persistent_kernel(
+    const float *__restrict__ res, const float *__restrict__ img, const int *__restrict__ dirty,
+    u64 *__restrict__ keys, int64_t N, int64_t A, int64_t Ns, int NBLK, int NAT, int KC, int stride,
+    int64_t LT, int64_t tasks_per_wg, int stagger) {
+    constexpr int NT = TA / 32;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float *img_s = reinterpret_cast<float *>(smem);  // KC * TA floats
+    const int WIN = KC + LAGS_PER_WAVE + 16;
+    float *win_all = img_s + (size_t)KC * TA;
+    if (stagger) {
+        // Two wavefronts share each SIMD's matrix pipe and run the same program: started together
+        // they reach their (pipe-idle) epilogues together.  Delay the one in the odd wave slot by
+        // about half a cell so that one computes while the other finishes a cell.
+        const unsigned slot = __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 4);  // HW_ID.WAVE_ID
+        if (slot & 1) {
+            for (int z = 0; z < stagger; ++z) __builtin_amdgcn_s_sleep(127);
+        }
+    }
+    int *counter = reinterpret_cast<int *>(win_all + (size_t)WAVES * WIN);  // inside the trailing pad
+
+    const int tid = threadIdx.x;
+    const int w = tid >> 6;
+    const int lane = tid & 63;
+    const int i = lane & 31;
+    const int h = lane >> 5;
+    float *win_s = win_all + (size_t)w * WIN;
+
+    const int64_t T = LT * NAT;
+    int64_t lo = (int64_t)blockIdx.x * tasks_per_wg;
+    int64_t hi = lo + tasks_per_wg;
+    if (hi > T) hi = T;
+
+    // Every loop below has a trip bound every wavefront reaches (a persistent kernel must drain).
+    for (int seg = 0; seg <= NAT && lo < hi; ++seg) {  // uniform across the workgroup
+        const int tile = (int)(lo / LT);
+        int64_t seg_end = (int64_t)(tile + 1) * LT;
+        if (seg_end > hi) seg_end = hi;
+        const int n_here = (int)(seg_end - lo);
+        const int64_t lagtask0 = lo - (int64_t)tile * LT;
+
+        stage_image<DMA>(reinterpret_cast<const f32x4 *>(img) + (size_t)tile * (KC * TA / 4), img_s,
+                         KC * TA / 4, tid);
+        if (tid == 0) *counter = 0;
+        __syncthreads();
+
+        // A wavefront always holds its NEXT cell's residual window in registers (3 x 16 B per lane,
+        // loaded while the current cell's MFMAs run), so no cell starts with an exposed HBM/L2 round trip.
+        constexpr int WQ = 3;  // ceil((KC_MAX + 64) / 4 / 64)
+        const int w4 = (KC + LAGS_PER_WAVE) / 4;
+        f32x4 pre[WQ];
+        int64_t nb = 0;       // segment of the prefetched cell
+        int nblk = -1;        // its lag block, -1 = none (queue drained or empty slot)
+        int q = n_here;
+        auto grab = [&]() {
+            int v = 0;
+            if (lane == 0) v = atomicAdd(counter, 1);
+            q = __builtin_amdgcn_readfirstlane(v);  // scalar from here on: the control flow is uniform
+            nblk = -1;
+            if (q < n_here) {
+                const int64_t lagtask = lagtask0 + q;
+                nb = lagtask / stride;
+                const int c = (int)(lagtask - nb * stride);
+                int first = 0, count = NBLK;
+                if (dirty) {
+                    first = __builtin_amdgcn_readfirstlane(dirty[2 * nb]);
+                    count = __builtin_amdgcn_readfirstlane(dirty[2 * nb + 1]);
+                }
+                if (c < count) {  // else: an empty slot of this segment's dirty run
+                    nblk = first + c;
+                    const f32x4 *wsrc =
+                        reinterpret_cast<const f32x4 *>(res + nb * Ns + (int64_t)nblk * LAGS_PER_WAVE);
+#pragma unroll
+                    for (int u = 0; u < WQ; ++u)
+                        if (lane + 64 * u < w4) pre[u] = wsrc[lane + 64 * u];
+                }
+            }
+        };
+        grab();
+        for (int trip = 0; trip <= n_here && q < n_here; ++trip) {
+            const int blk = nblk;
+            const int64_t b = nb;
+            if (blk >= 0) {
+                f32x4 *wdst = reinterpret_cast<f32x4 *>(win_s);
+#pragma unroll
+                for (int u = 0; u < WQ; ++u)
+                    if (lane + 64 * u < w4) wdst[lane + 64 * u] = pre[u];
+            }
+            grab();  // next cell's window goes in flight now, lands while this cell computes
+            if (blk >= 0) {
+                const int64_t t0 = (int64_t)blk * LAGS_PER_WAVE;
+                f32x16 acc[2][NT];
+#pragma unroll
+                for (int s = 0; s < 2; ++s)
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) acc[s][nt][r] = 0.0f;
+                mfma_chunk<TA>(img_s, win_s, KC, i, h, acc);
+                const u64 key = cell_key<TA>(acc, tile, t0, N, A, i, h);
+                if (lane == 0) keys[(b * NBLK + blk) * NAT + tile] = key;
+            }
+        }
+        __syncthreads();  // every wavefront is done with this image (and with the counter)
+        lo = seg_end;
     }
 }
 
@@ -546,7 +704,6 @@ Workspace carve(const Geom &g, int path, char *base) {
 
 int check_shape(int64_t B, int64_t N, int64_t A, int64_t L, int K) {
     if (B < 0 || N <= 0 || A <= 0 || L <= 0 || K < 0) return fail(MP_ERR_ARG, "bad shape%s");
-    if (B > 65535) return fail(MP_ERR_ARG, "batch > 65535 per call: split the batch%s");
     if ((unsigned long long)A * (unsigned long long)N > 0xfffffffeull)
         return fail(MP_ERR_ARG, "A * N must be < 2^32 - 1%s");
     if (L > (1 << 24)) return fail(MP_ERR_ARG, "atom size too large%s");
@@ -555,12 +712,12 @@ int check_shape(int64_t B, int64_t N, int64_t A, int64_t L, int K) {
 
 // image + window + the pad the pipelined loop's last (unused) prefetch may touch
 size_t lds_bytes(const Geom &g) {
-    return ((size_t)g.KC * g.TA + g.KC + WG_LAGS + 16) * sizeof(float) + (size_t)(g.TA + 64) * 16;
+    return ((size_t)g.KC * g.TA + (size_t)WAVES * (g.KC + LAGS_PER_WAVE + 16)) * sizeof(float) +
+           (size_t)(g.TA + 64) * 16;
 }
 
 template <int TA, bool STORE_FM, bool DMA>
-int launch_correlate_t(const Geom &g, const Workspace &w, const int *dirty, int ngrp, float *fm,
-                       hipStream_t st) {
+int launch_correlate_t(const Geom &g, const Workspace &w, const int *dirty, float *fm, hipStream_t st) {
     auto kern = correlate_mfma_kernel<TA, STORE_FM, DMA>;
     const size_t lds = lds_bytes(g);
     static thread_local size_t configured = 0;
@@ -569,25 +726,79 @@ int launch_correlate_t(const Geom &g, const Workspace &w, const int *dirty, int 
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         configured = lds;
     }
-    dim3 grid(ngrp, g.NAT, (unsigned)g.B);
-    hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, w.res, w.img, dirty, w.keys, fm, g.N, g.A, g.Ns,
-                       g.NBLK, g.NAT, g.KC, g.NCH);
+    const int stride = dirty ? g.MAXC : g.NBLK;
+    const int64_t tasks = g.B * (int64_t)stride;
+    dim3 grid((unsigned)((tasks + WAVES - 1) / WAVES), g.NAT);
+    hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, w.res, w.img, dirty, w.keys, fm, g.N, g.A, g.Ns, g.B,
+                       g.NBLK, g.NAT, g.KC, g.NCH, stride);
+    HIP_TRY(hipGetLastError());
+    return MP_OK;
+}
+
+int g_num_cus = 0;
+int num_cus() {
+    if (g_num_cus == 0) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
+            g_num_cus = prop.multiProcessorCount;
+        if (g_num_cus <= 0) g_num_cus = 256;
+    }
+    return g_num_cus;
+}
+
+template <int TA, bool DMA>
+int launch_persistent_t(const Geom &g, const Workspace &w, const int *dirty, int stagger, hipStream_t st) {
+    auto kern = correlate_persistent_kernel<TA, DMA>;
+    const size_t lds = lds_bytes(g);
+    static thread_local size_t configured = 0;
+    if (lds > configured) {
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        configured = lds;
+    }
+    const int stride = dirty ? g.MAXC : g.NBLK;
+    const int64_t LT = g.B * (int64_t)stride;
+    const int64_t T = LT * g.NAT;
+    const int wgs_per_cu = (int)(160 * 1024 / lds) < 1 ? 1 : (int)(160 * 1024 / lds);
+    int64_t grid = (int64_t)num_cus() * (wgs_per_cu > 2 ? 2 : wgs_per_cu);
+    if (grid > (T + WAVES - 1) / WAVES) grid = (T + WAVES - 1) / WAVES;
+    const int64_t per = (T + grid - 1) / grid;
+    grid = (T + per - 1) / per;
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), lds, st, w.res, w.img, dirty, w.keys, g.N, g.A,
+                       g.Ns, g.NBLK, g.NAT, g.KC, stride, LT, per, stagger);
     HIP_TRY(hipGetLastError());
     return MP_OK;
 }
 
 template <bool STORE_FM>
-int launch_correlate(const Geom &g, const Workspace &w, const int *dirty, int ngrp, float *fm, int flags,
+int launch_correlate(const Geom &g, const Workspace &w, const int *dirty, float *fm, int flags,
                      hipStream_t st) {
     const bool dma = !(flags & MP_FLAG_NO_DMA);
+    if (!STORE_FM && g.NCH == 1 && !(flags & MP_FLAG_NO_PERSISTENT)) {
+        // s_sleep(127) = 8128 cycles; half a cell at one wave per SIMD is ~8k * KC/512 * TA/32 ... cycles
+        // measured (scripts/ab_flags.py): -3 % time on incremental launches (all workgroups start
+        // together and run only ~8 cells each), no effect on full passes (hundreds of cells drift apart)
+        const int stagger = (dirty && !(flags & MP_FLAG_NO_STAGGER)) ? (g.TA == 32 ? 2 : 4) : 0;
+        if (g.TA == 32)
+            return dma ? launch_persistent_t<32, true>(g, w, dirty, stagger, st)
+                       : launch_persistent_t<32, false>(g, w, dirty, stagger, st);
+        return dma ? launch_persistent_t<64, true>(g, w, dirty, stagger, st)
+                   : launch_persistent_t<64, false>(g, w, dirty, stagger, st);
+    }
     if (g.TA == 32)
-        return dma ? launch_correlate_t<32, STORE_FM, true>(g, w, dirty, ngrp, fm, st)
-                   : launch_correlate_t<32, STORE_FM, false>(g, w, dirty, ngrp, fm, st);
-    return dma ? launch_correlate_t<64, STORE_FM, true>(g, w, dirty, ngrp, fm, st)
-               : launch_correlate_t<64, STORE_FM, false>(g, w, dirty, ngrp, fm, st);
+        return dma ? launch_correlate_t<32, STORE_FM, true>(g, w, dirty, fm, st)
+                   : launch_correlate_t<32, STORE_FM, false>(g, w, dirty, fm, st);
+    return dma ? launch_correlate_t<64, STORE_FM, true>(g, w, dirty, fm, st)
+               : launch_correlate_t<64, STORE_FM, false>(g, w, dirty, fm, st);
 }
 
-int tile_atoms(int flags) { return (flags & MP_FLAG_TA32) ? 32 : 64; }
+// Default tile: 32 atoms (64 KiB image, two workgroups per CU so one stages while the other computes);
+// measured faster than 64 on MI355X for both the full and the incremental pass.
+int tile_atoms(int flags) {
+    if (flags & MP_FLAG_TA64) return 64;
+    return 32;
+}
 
 int launch_naive(const Geom &g, const Workspace &w, const float *du, const int *dirty, int nblk_grid,
                  float *fm, hipStream_t st) {
@@ -674,6 +885,8 @@ int mp_encode_f32(const float *signal, int64_t B, int64_t N, const float *dict_u
     if (path == MP_PATH_FFT) return fail(MP_ERR_UNSUPPORTED, "MP_PATH_FFT is not built yet%s");
     if (path != MP_PATH_DIRECT && path != MP_PATH_INCREMENTAL && path != MP_PATH_NAIVE)
         return fail(MP_ERR_ARG, "unknown path%s");
+    if (path == MP_PATH_NAIVE && (B > 65535 || A > 65535))
+        return fail(MP_ERR_ARG, "MP_PATH_NAIVE: B and A must be <= 65535%s");
     if (B == 0) return MP_OK;
     if (!signal || !dict_unit || !workspace) return fail(MP_ERR_ARG, "null pointer%s");
     if (K > 0 && (!out_atom || !out_lag || !out_gain)) return fail(MP_ERR_ARG, "null output%s");
@@ -696,7 +909,7 @@ int mp_encode_f32(const float *signal, int64_t B, int64_t N, const float *dict_u
         if (naive)
             rc = launch_naive(g, w, dict_unit, dirty, g.NBLK, nullptr, st);
         else
-            rc = launch_correlate<false>(g, w, dirty, full ? g.NGRP_FULL : g.NGRP_INC, nullptr, flags, st);
+            rc = launch_correlate<false>(g, w, dirty, nullptr, flags, st);
         g_prof.end(st);
         if (rc) return rc;
         g_prof.begin(PROF_SELECT, st);
@@ -728,7 +941,7 @@ int mp_feature_map_f32(const float *residual, int64_t B, int64_t N, const float 
     hipStream_t st = static_cast<hipStream_t>(stream);
     rc = stage_inputs(g, w, MP_PATH_DIRECT, residual, dict_unit, st);
     if (rc) return rc;
-    return launch_correlate<true>(g, w, nullptr, g.NGRP_FULL, fm, 0, st);
+    return launch_correlate<true>(g, w, nullptr, fm, 0, st);
 }
 
 int mp_scatter_f32(const int64_t *atom, const int64_t *batch, const int64_t *lag, const float *gain,

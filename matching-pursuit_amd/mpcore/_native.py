@@ -18,6 +18,9 @@ MP_PATH_INCREMENTAL = 2
 MP_PATH_NAIVE = 8
 MP_FLAG_NO_DMA = 1
 MP_FLAG_TA32 = 2
+MP_FLAG_TA64 = 4
+MP_FLAG_NO_PERSISTENT = 8
+MP_FLAG_NO_STAGGER = 16
 
 EXPORTS = (
     "mp_version", "mp_last_error", "mp_workspace_bytes", "mp_unit_norm_f32", "mp_encode_f32",

@@ -19,7 +19,7 @@ from ._native import NativeError
 __all__ = [
     "build_scatter_segments", "flatten_atom_dict", "sparse_code", "dictionary_learning_step",
     "sparse_feature_map", "sparse_coding_loss", "SparseCodingLoss", "unit_norm", "torch_conv",
-    "fft_convolve", "EventList", "encode_packed",
+    "fft_convolve", "EventList", "encode_packed", "first_selection_order", "group_events_by_atom",
 ]
 
 
@@ -264,16 +264,9 @@ def sparse_code(
     flattened = flatten_atom_dict(instances)
     # packed arrays in the flattened (grouped-by-atom) order, so scatter(shape, events) is one kernel
     if len(flattened):
-        B, K = atom.shape
-        step_of = {}
-        order = []
-        # flattened order = for each atom key (first-selection order): its events in (step, batch) order
-        for i in range(K):
-            for j in range(B):
-                step_of.setdefault(atom_l[j][i], []).append(j * K + i)
-        for key in instances.keys():
-            order.extend(step_of[key])
-        idx = torch.tensor(order, dtype=torch.int64, device=dev)
+        K = atom.shape[1]
+        perm, _ = group_events_by_atom(atom.cpu(), list(instances.keys()), n_atoms)
+        idx = perm.to(dev)
         flattened.packed = dict(atom=atom.reshape(-1)[idx], batch=idx // K, lag=lag.reshape(-1)[idx],
                                 gain=gain.reshape(-1)[idx], dict_unit=d_unit, out_device=out_dev)
 
@@ -334,6 +327,34 @@ def _sparse_code_dense(signal, d_unit, n_steps, approx, extract_atom_embedding, 
     return torch.cat(atoms, 1), torch.cat(lags, 1), torch.cat(gains, 1).float(), residual, embeddings
 
 
+def first_selection_order(atom):
+    """atom [B, K] (selection order per segment) -> atoms in the order the reference's `instances`
+    dict first sees them: steps outer, batch inner (:269, :311, :321)."""
+    order, seen = [], set()
+    for a in atom.t().reshape(-1).tolist():
+        if a not in seen:
+            seen.add(a)
+            order.append(a)
+    return order
+
+
+def group_events_by_atom(atom, order, n_atoms):
+    """Permutation of the flat [B*K] event index (b*K + k) that lists events grouped by atom in
+    `order`, each group in (step, batch) order -- the layout of flatten_atom_dict (:61-65) -- and the
+    number of events per group.  Atoms of `order` absent from `atom` (another rank's) get 0."""
+    B, K = atom.shape
+    rank_of = torch.full((n_atoms,), len(order), dtype=torch.int64)
+    if len(order):
+        rank_of[torch.tensor(order, dtype=torch.int64)] = torch.arange(len(order))
+    step_idx = torch.arange(K)[None, :].expand(B, K)
+    batch_idx = torch.arange(B)[:, None].expand(B, K)
+    r = rank_of[atom]
+    sort_key = (r * K + step_idx) * max(B, 1) + batch_idx
+    perm = torch.argsort(sort_key.reshape(-1), stable=True)
+    counts = torch.bincount(r.reshape(-1), minlength=len(order) + 1).tolist()[: len(order)]
+    return perm, counts
+
+
 # --------------------------------------------------------------------------------------------
 # dictionary_learning_step  (modules/matchingpursuit.py:348-419)
 # --------------------------------------------------------------------------------------------
@@ -382,26 +403,11 @@ def dictionary_learning_step(
 
     # global (step-major, batch-minor) first-selection order of atoms (:391, dict insertion order)
     from . import dist as _dist
-    atom_global, batch_offset = _dist.gather_batch(atom, process_group)
-    atom_host = atom_global.cpu()
-    order = []
-    seen = set()
-    for a in atom_host.t().reshape(-1).tolist():  # transpose: steps outer, batch inner
-        if a not in seen:
-            seen.add(a)
-            order.append(a)
-
-    # local events sorted by (rank of atom in `order`, step, batch): one contiguous slice per atom
-    rank_of = torch.full((n_atoms,), len(order), dtype=torch.int64)
-    rank_of[torch.tensor(order, dtype=torch.int64)] = torch.arange(len(order))
-    local_atom = atom.cpu()
-    step_idx = torch.arange(K)[None, :].expand(batch, K)
-    batch_idx = torch.arange(batch)[:, None].expand(batch, K)
-    sort_key = (rank_of[local_atom] * K + step_idx) * max(batch, 1) + batch_idx
-    perm = torch.argsort(sort_key.reshape(-1))
-    counts = torch.bincount(rank_of[local_atom].reshape(-1), minlength=len(order) + 1).tolist()
+    atom_global, _ = _dist.gather_batch(atom, process_group)
+    order = first_selection_order(atom_global.cpu())
+    perm, counts = group_events_by_atom(atom.cpu(), order, n_atoms)
     perm_d = perm.to(dev)
-    ev_batch = batch_idx.reshape(-1).to(dev)[perm_d]
+    ev_batch = (perm_d // K)
     ev_lag = lag.reshape(-1)[perm_d]
     ev_rows = rows.reshape(-1, atom_size)[perm_d]
     ev_norm = anorm.reshape(-1)[perm_d]

@@ -66,9 +66,12 @@ for name, (A, L, N, B, K, n_ev, seed) in shapes.items():
     want = mp_oracle.encode(x, du, K)
     for tag, path, flags in [("naive", nat.MP_PATH_NAIVE, 0), ("direct", nat.MP_PATH_DIRECT, 0),
                              ("direct_nodma", nat.MP_PATH_DIRECT, nat.MP_FLAG_NO_DMA),
-                             ("direct_ta32", nat.MP_PATH_DIRECT, nat.MP_FLAG_TA32),
-                             ("incremental", nat.MP_PATH_INCREMENTAL, 0)]:
+                             ("direct_ta64", nat.MP_PATH_DIRECT, nat.MP_FLAG_TA64),
+                             ("incremental", nat.MP_PATH_INCREMENTAL, 0),
+                             ("incremental_np", nat.MP_PATH_INCREMENTAL, 8),
+                             ("incremental_np_nodma_ta64", nat.MP_PATH_INCREMENTAL, 8 | 1 | 4)]:
         try:
+            print(f"   ... {name}/{tag}", flush=True)
             out = nat.encode(torch.from_numpy(x).to(DEV), torch.from_numpy(du).to(DEV), K, path=path, flags=flags)
             torch.cuda.synchronize()
             report_enc(f"{name}/{tag}", [t.cpu().numpy() for t in out], want)
@@ -82,9 +85,13 @@ d = synth.make_dictionary(A, L, seed=1000)
 x = torch.from_numpy(synth.make_segments(B, N, d, n_events=192, seed=1002)).to(DEV)
 du = nat.unit_norm(torch.from_numpy(d).to(DEV))
 ref = None
-for tag, path, flags, k in [("incremental", 2, 0, K), ("incremental_nodma", 2, 1, K), ("incremental_ta32", 2, 2, K),
-                            ("incremental_ta32_nodma", 2, 3, K),
-                            ("direct", 0, 0, 8), ("direct_nodma", 0, 1, 8), ("direct_ta32", 0, 2, 8)]:
+for tag, path, flags, k in [("incremental", 2, 0, K), ("incremental_nodma", 2, 1, K), ("incremental_ta64", 2, 4, K),
+                            ("incremental_nostagger", 2, 16, K), ("incremental_nostagger_ta64", 2, 20, K),
+                            ("incremental_np", 2, 8, K),
+                            ("direct", 0, 0, 8), ("direct_nodma", 0, 1, 8), ("direct_ta64", 0, 4, 8),
+                            ("direct_nostagger", 0, 16, 8), ("direct_nostagger_ta64", 0, 20, 8),
+                            ("direct_np", 0, 8, 8)]:
+    print(f"   ... timing {tag}", flush=True)
     nat.encode(x, du, 2, path=path, flags=flags)
     torch.cuda.synchronize()
     t0 = time.perf_counter()

@@ -23,9 +23,11 @@ PATHS = [
     ("naive", nat.MP_PATH_NAIVE, 0),
     ("direct", nat.MP_PATH_DIRECT, 0),
     ("direct_nodma", nat.MP_PATH_DIRECT, nat.MP_FLAG_NO_DMA),
-    ("direct_ta32", nat.MP_PATH_DIRECT, nat.MP_FLAG_TA32),
+    ("direct_ta64", nat.MP_PATH_DIRECT, nat.MP_FLAG_TA64),
     ("incremental", nat.MP_PATH_INCREMENTAL, 0),
-    ("incremental_ta32_nodma", nat.MP_PATH_INCREMENTAL, nat.MP_FLAG_TA32 | nat.MP_FLAG_NO_DMA),
+    ("incremental_nonpersistent", nat.MP_PATH_INCREMENTAL, nat.MP_FLAG_NO_PERSISTENT),
+    ("direct_nonpersistent_nodma", nat.MP_PATH_DIRECT, nat.MP_FLAG_NO_PERSISTENT | nat.MP_FLAG_NO_DMA),
+    ("incremental_ta64_nodma", nat.MP_PATH_INCREMENTAL, nat.MP_FLAG_TA64 | nat.MP_FLAG_NO_DMA),
 ]
 
 # name: (A, L, N, B, K, n_events, seed)
@@ -185,7 +187,7 @@ def test_c2_incremental_equals_direct_bitwise(c2_inputs):
     K = 24
     inc = nat.encode(x, du, K, path=nat.MP_PATH_INCREMENTAL)
     full = nat.encode(x, du, K, path=nat.MP_PATH_DIRECT)
-    ta32 = nat.encode(x, du, K, path=nat.MP_PATH_INCREMENTAL, flags=nat.MP_FLAG_TA32)
+    ta32 = nat.encode(x, du, K, path=nat.MP_PATH_INCREMENTAL, flags=nat.MP_FLAG_TA64)
     torch.cuda.synchronize()
     for p, q, r in zip(inc, full, ta32):
         assert torch.equal(p, q) and torch.equal(p, r)
