@@ -160,9 +160,14 @@ def main():
     ap.add_argument("--flags", type=int, default=0)
     ap.add_argument("--no-variants", action="store_true", help="skip the direct-path variant leg")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
+    ap.add_argument("--backend", default=None, help="torch.distributed backend (default nccl = RCCL)")
+    ap.add_argument("--share-device", action="store_true",
+                    help="rehearsal only: every rank uses cuda:0 (with --backend gloo on a one-GPU box)")
     args = ap.parse_args()
 
-    rank, world, local_rank = mpdist.init_from_env()
+    if args.share_device:
+        os.environ["LOCAL_RANK"] = "0"
+    rank, world, local_rank = mpdist.init_from_env(backend=args.backend)
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run "
                          f"--nproc-per-node {args.gpus}")

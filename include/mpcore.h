@@ -36,7 +36,11 @@ extern "C" {
 /* How the per-iteration correlation is scheduled.  All paths select bit-identical events. */
 #define MP_PATH_DIRECT 0      /* full A x N correlation every iteration (what the reference
                                  recomputes each step, modules/matchingpursuit.py:275-277)  */
-#define MP_PATH_FFT 1         /* reserved: FFT correlation (modules/conv.py:11-53)          */
+#define MP_PATH_FFT 1         /* FFT correlation (modules/conv.py:11-53) as an overlap-save SCREEN,
+                                 the few cells that can hold the maximum re-evaluated exactly:
+                                 same events as MP_PATH_DIRECT.  A segment whose screen
+                                 overflowed (> 32 inexact contender cells in one step) gets
+                                 out_gain[b, :] = NaN: re-encode it with MP_PATH_INCREMENTAL    */
 #define MP_PATH_INCREMENTAL 2 /* full correlation once, then only the lags an event touched
                                  ([p-L+1, p+L-1]); untouched block maxima are reused        */
 #define MP_PATH_NAIVE 8       /* one-thread-per-lag fmaf chain, no MFMA: validation only    */
@@ -100,6 +104,14 @@ int mp_encode_f32(const float *signal, int64_t B, int64_t N, const float *dict_u
 int mp_feature_map_f32(const float *residual, int64_t B, int64_t N, const float *dict_unit,
                        int64_t A, int64_t L, float *fm, void *workspace, size_t workspace_bytes,
                        void *stream);
+
+/*
+ * Test hook: batched complex FFT of 2^log2_m points (8 <= log2_m <= 14), unscaled, forward or
+ * inverse -- the radix-4 Stockham transform MP_PATH_FFT is built on.  in/out: [batch, 2^log2_m]
+ * interleaved (re, im) fp32; workspace >= 8 * 2^log2_m bytes (twiddle table).
+ */
+int mp_fft_c2c_f32(const float *in, float *out, int log2_m, int64_t batch, int inverse, void *workspace,
+                   void *stream);
 
 /*
  * Decoder: out[batch[e], lag[e] + i] += dict_unit[atom[e], i] * gain[e], i < L, cropped to

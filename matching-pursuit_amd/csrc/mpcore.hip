@@ -97,7 +97,7 @@ struct Geom {
     int MAXC;      // most 64-lag blocks one subtraction can dirty
 };
 
-Geom make_geom(int64_t B, int64_t N, int64_t A, int64_t L, int TA) {
+Geom make_geom(int64_t B, int64_t N, int64_t A, int64_t L, int TA, int64_t window = 0) {
     Geom g;
     g.B = B; g.N = N; g.A = A; g.L = L; g.TA = TA;
     g.NAT = (int)((A + TA - 1) / TA);
@@ -106,7 +106,9 @@ Geom make_geom(int64_t B, int64_t N, int64_t A, int64_t L, int TA) {
     g.KC = Lp < KC_MAX ? Lp : KC_MAX;
     g.NCH = (Lp + g.KC - 1) / g.KC;
     g.Lpp = g.NCH * g.KC;
-    g.Ns = round_up((int64_t)g.NBLK * LAGS_PER_WAVE + g.Lpp + 64, 64);
+    // rows are readable (as zeros) far enough past N for the longest window any kernel loads
+    const int64_t reach = g.Lpp > window ? g.Lpp : window;
+    g.Ns = round_up((int64_t)g.NBLK * LAGS_PER_WAVE + reach + 64, 64);
     // a subtraction at lag p changes lags [p-L+1, p+L-1]: at most this many 64-lag blocks
     int nb = (int)((2 * L - 2) / LAGS_PER_WAVE) + 2;
     if (nb > g.NBLK) nb = g.NBLK;
@@ -672,11 +674,18 @@ __global__ void gather_sum_kernel(const float *__restrict__ x, int64_t N, const 
 // ------------------------------------------------------------------------------------------------
 // Workspace carving (all offsets multiples of 256 bytes)
 // ------------------------------------------------------------------------------------------------
+#include "mpfft.inc"
+
 struct Workspace {
     float *res;
     float *img;
     u64 *keys;
     int *dirty;
+    // FFT path only
+    cpx *tw, *pspec, *xspec;
+    float *wnorm, *ceps;
+    int *cont, *ncont, *overflow;
+    u64 *ekeys;
     size_t bytes;
 };
 
@@ -694,6 +703,33 @@ Workspace carve(const Geom &g, int path, char *base) {
     size_t cells = naive ? (size_t)g.A : (size_t)g.NAT;
     size_t o_keys = take((size_t)g.B * g.NBLK * cells * sizeof(u64));
     size_t o_dirty = take((size_t)g.B * 2 * sizeof(int));
+    w.tw = w.pspec = w.xspec = nullptr;
+    w.wnorm = w.ceps = nullptr;
+    w.cont = w.ncont = w.overflow = nullptr;
+    w.ekeys = nullptr;
+    if (path == MP_PATH_FFT) {
+        FftGeom f;
+        if (make_fft_geom(g, &f)) {
+            size_t o_tw = take((size_t)f.M * sizeof(cpx));
+            size_t o_ps = take((size_t)g.NAT * f.NPT * f.M * sizeof(cpx));
+            size_t o_xs = take((size_t)g.B * f.NW * f.M * sizeof(cpx));
+            size_t o_wn = take((size_t)g.B * f.NW * sizeof(float));
+            size_t o_ce = take((size_t)g.B * g.NBLK * g.NAT * sizeof(float));
+            size_t o_co = take((size_t)g.B * MAXCONT * sizeof(int));
+            size_t o_nc = take((size_t)g.B * sizeof(int));
+            size_t o_ov = take((size_t)g.B * sizeof(int));
+            size_t o_ek = take((size_t)g.B * (MAXCONT + 1) * sizeof(u64));
+            w.tw = reinterpret_cast<cpx *>(base + o_tw);
+            w.pspec = reinterpret_cast<cpx *>(base + o_ps);
+            w.xspec = reinterpret_cast<cpx *>(base + o_xs);
+            w.wnorm = reinterpret_cast<float *>(base + o_wn);
+            w.ceps = reinterpret_cast<float *>(base + o_ce);
+            w.cont = reinterpret_cast<int *>(base + o_co);
+            w.ncont = reinterpret_cast<int *>(base + o_nc);
+            w.overflow = reinterpret_cast<int *>(base + o_ov);
+            w.ekeys = reinterpret_cast<u64 *>(base + o_ek);
+        }
+    }
     w.res = reinterpret_cast<float *>(base + o_res);
     w.img = reinterpret_cast<float *>(base + o_img);
     w.keys = reinterpret_cast<u64 *>(base + o_keys);
@@ -826,6 +862,101 @@ int stage_inputs(const Geom &g, const Workspace &w, int path, const float *signa
     return MP_OK;
 }
 
+// ---- FFT path driver ---------------------------------------------------------------------------
+Geom make_geom_for(int64_t B, int64_t N, int64_t A, int64_t L, int path, int flags) {
+    if (path == MP_PATH_FFT) {
+        Geom g0 = make_geom(B, N, A, L, 32);
+        FftGeom f;
+        if (make_fft_geom(g0, &f)) return make_geom(B, N, A, L, 32, f.M);
+        return g0;
+    }
+    return make_geom(B, N, A, L, tile_atoms(flags));
+}
+
+#define MP_FFT_DISPATCH(LOGM, CALL)                                  \
+    switch (LOGM) {                                                  \
+        case 8: { constexpr int LG = 8; CALL; } break;               \
+        case 9: { constexpr int LG = 9; CALL; } break;               \
+        case 10: { constexpr int LG = 10; CALL; } break;             \
+        case 11: { constexpr int LG = 11; CALL; } break;             \
+        case 12: { constexpr int LG = 12; CALL; } break;             \
+        case 13: { constexpr int LG = 13; CALL; } break;             \
+        case 14: { constexpr int LG = 14; CALL; } break;             \
+        default: return fail(MP_ERR_UNSUPPORTED, "FFT size out of range%s"); \
+    }
+
+template <typename K>
+int fft_lds_attr(K kern, size_t bytes) {
+    if (bytes > 64 * 1024)
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+    return MP_OK;
+}
+
+constexpr float FFT_TAU = 1.0e-4f;  // screen error bound per unit of window norm
+
+int encode_fft(const Geom &g, const Workspace &w, const float *du, int K, int flags, int64_t *out_atom,
+               int64_t *out_lag, float *out_gain, hipStream_t st) {
+    FftGeom f;
+    if (!make_fft_geom(g, &f))
+        return fail(MP_ERR_UNSUPPORTED, "MP_PATH_FFT: atoms longer than 5398 samples need MP_PATH_INCREMENTAL%s");
+    if (g.B > 65535) return fail(MP_ERR_ARG, "MP_PATH_FFT: batch > 65535 per call%s");
+    const size_t lds = (size_t)f.M * sizeof(cpx);
+    const int64_t n_cells = (int64_t)g.NBLK * g.NAT;
+    const int npairs = g.NAT * f.NPT;
+    int rc;
+    hipLaunchKernelGGL(fft_twiddle_kernel, dim3((f.M + 255) / 256), dim3(256), 0, st, w.tw, f.M);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemsetAsync(w.overflow, 0, (size_t)g.B * sizeof(int), st));
+    MP_FFT_DISPATCH(f.logM, {
+        if ((rc = fft_lds_attr(fft_dict_kernel<LG>, lds))) return rc;
+        if ((rc = fft_lds_attr(fft_window_kernel<LG>, lds))) return rc;
+        if ((rc = fft_lds_attr(fft_correlate_kernel<LG>, lds))) return rc;
+        hipLaunchKernelGGL(fft_dict_kernel<LG>, dim3(npairs), dim3(256), lds, st, du, g.A, g.L, w.tw, w.pspec);
+    })
+    HIP_TRY(hipGetLastError());
+    const bool dma = !(flags & MP_FLAG_NO_DMA);
+    const size_t lds_ref = lds_bytes(g);
+    if (dma) { if ((rc = fft_lds_attr(fft_refine_kernel<true>, lds_ref))) return rc; }
+    else { if ((rc = fft_lds_attr(fft_refine_kernel<false>, lds_ref))) return rc; }
+
+    for (int k = 0; k < K; ++k) {
+        const int *dirty = k == 0 ? nullptr : w.dirty;
+        const int nw = k == 0 ? f.NW : 1;
+        g_prof.begin(k == 0 ? PROF_CORR_FULL : PROF_CORR_INC, st);
+        MP_FFT_DISPATCH(f.logM, {
+            hipLaunchKernelGGL(fft_window_kernel<LG>, dim3(nw, (unsigned)g.B), dim3(256), lds, st, w.res, g.Ns,
+                               dirty, w.tw, w.xspec, w.wnorm, f.V, f.NW);
+            hipLaunchKernelGGL(fft_correlate_kernel<LG>, dim3(nw, g.NAT, (unsigned)g.B), dim3(256), lds, st,
+                               w.xspec, w.pspec, w.tw, dirty, w.wnorm, w.keys, w.ceps, g.N, g.A, g.NBLK, g.NAT,
+                               f.V, f.NW, FFT_TAU);
+        })
+        g_prof.end(st);
+        HIP_TRY(hipGetLastError());
+        g_prof.begin(PROF_SELECT, st);
+        hipLaunchKernelGGL(fft_select_a_kernel, dim3((unsigned)g.B), dim3(256), 0, st, w.keys, w.ceps, n_cells,
+                           w.cont, w.ncont, w.ekeys, w.overflow);
+        if (dma)
+            hipLaunchKernelGGL(fft_refine_kernel<true>, dim3(MAXCONT, (unsigned)g.B), dim3(256), lds_ref, st, w.res,
+                               w.img, w.cont, w.ncont, w.keys, w.ceps, w.ekeys, g.N, g.A, g.Ns, g.NBLK, g.NAT,
+                               g.KC, g.NCH);
+        else
+            hipLaunchKernelGGL(fft_refine_kernel<false>, dim3(MAXCONT, (unsigned)g.B), dim3(256), lds_ref, st, w.res,
+                               w.img, w.cont, w.ncont, w.keys, w.ceps, w.ekeys, g.N, g.A, g.Ns, g.NBLK, g.NAT,
+                               g.KC, g.NCH);
+        hipLaunchKernelGGL(select_subtract_kernel, dim3((unsigned)g.B), dim3(256), 0, st, w.ekeys,
+                           (int64_t)(MAXCONT + 1), w.res, du, w.dirty, out_atom, out_lag, out_gain, g.N, g.L,
+                           g.Ns, g.NBLK, K, k);
+        g_prof.end(st);
+        HIP_TRY(hipGetLastError());
+    }
+    if (K > 0) {
+        hipLaunchKernelGGL(fft_mark_overflow_kernel, dim3((unsigned)g.B), dim3(64), 0, st, w.overflow, out_gain, K);
+        HIP_TRY(hipGetLastError());
+    }
+    return MP_OK;
+}
+
 }  // namespace
 
 // =================================================================================================
@@ -839,6 +970,7 @@ const char *mp_last_error(void) { return g_err; }
 
 size_t mp_workspace_bytes(int64_t B, int64_t N, int64_t A, int64_t L, int K, int path) {
     if (check_shape(B, N, A, L, K) != MP_OK) return 0;
+    if (path == MP_PATH_FFT) return carve(make_geom_for(B, N, A, L, path, 0), path, nullptr).bytes;
     size_t b64 = carve(make_geom(B, N, A, L, 64), path, nullptr).bytes;
     size_t b32 = carve(make_geom(B, N, A, L, 32), path, nullptr).bytes;
     return b64 > b32 ? b64 : b32;
@@ -882,8 +1014,7 @@ int mp_encode_f32(const float *signal, int64_t B, int64_t N, const float *dict_u
                   void *stream) {
     int rc = check_shape(B, N, A, L, K);
     if (rc) return rc;
-    if (path == MP_PATH_FFT) return fail(MP_ERR_UNSUPPORTED, "MP_PATH_FFT is not built yet%s");
-    if (path != MP_PATH_DIRECT && path != MP_PATH_INCREMENTAL && path != MP_PATH_NAIVE)
+    if (path != MP_PATH_DIRECT && path != MP_PATH_INCREMENTAL && path != MP_PATH_NAIVE && path != MP_PATH_FFT)
         return fail(MP_ERR_ARG, "unknown path%s");
     if (path == MP_PATH_NAIVE && (B > 65535 || A > 65535))
         return fail(MP_ERR_ARG, "MP_PATH_NAIVE: B and A must be <= 65535%s");
@@ -891,13 +1022,24 @@ int mp_encode_f32(const float *signal, int64_t B, int64_t N, const float *dict_u
     if (!signal || !dict_unit || !workspace) return fail(MP_ERR_ARG, "null pointer%s");
     if (K > 0 && (!out_atom || !out_lag || !out_gain)) return fail(MP_ERR_ARG, "null output%s");
     if (reinterpret_cast<uintptr_t>(workspace) % 256) return fail(MP_ERR_WORKSPACE, "workspace not 256-byte aligned%s");
-    Geom g = make_geom(B, N, A, L, tile_atoms(flags));
+    Geom g = make_geom_for(B, N, A, L, path, flags);
     Workspace w = carve(g, path, static_cast<char *>(workspace));
     if (w.bytes > workspace_bytes) return fail(MP_ERR_WORKSPACE, "workspace too small%s");
     hipStream_t st = static_cast<hipStream_t>(stream);
 
     rc = stage_inputs(g, w, path, signal, dict_unit, st);
     if (rc) return rc;
+
+    if (path == MP_PATH_FFT) {
+        rc = encode_fft(g, w, dict_unit, K, flags, out_atom, out_lag, out_gain, st);
+        if (rc) return rc;
+        if (out_residual) {
+            dim3 grid((unsigned)((N + 255) / 256 < 1024 ? (N + 255) / 256 : 1024), (unsigned)B);
+            hipLaunchKernelGGL(copy_residual_kernel, grid, dim3(256), 0, st, w.res, N, g.Ns, out_residual);
+            HIP_TRY(hipGetLastError());
+        }
+        return MP_OK;
+    }
 
     const bool naive = path == MP_PATH_NAIVE;
     const bool incremental = path == MP_PATH_INCREMENTAL;
@@ -942,6 +1084,26 @@ int mp_feature_map_f32(const float *residual, int64_t B, int64_t N, const float 
     rc = stage_inputs(g, w, MP_PATH_DIRECT, residual, dict_unit, st);
     if (rc) return rc;
     return launch_correlate<true>(g, w, nullptr, fm, 0, st);
+}
+
+int mp_fft_c2c_f32(const float *in, float *out, int log2_m, int64_t batch, int inverse, void *workspace,
+                   void *stream) {
+    if (!in || !out || !workspace || batch < 0 || log2_m < 8 || log2_m > 14)
+        return fail(MP_ERR_ARG, "mp_fft_c2c_f32: bad arguments (8 <= log2_m <= 14)%s");
+    if (batch == 0) return MP_OK;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const int M = 1 << log2_m;
+    cpx *tw = static_cast<cpx *>(workspace);
+    hipLaunchKernelGGL(fft_twiddle_kernel, dim3((M + 255) / 256), dim3(256), 0, st, tw, M);
+    const size_t lds = (size_t)M * sizeof(cpx);
+    int rc;
+    MP_FFT_DISPATCH(log2_m, {
+        if ((rc = fft_lds_attr(fft_c2c_kernel<LG>, lds))) return rc;
+        hipLaunchKernelGGL(fft_c2c_kernel<LG>, dim3((unsigned)batch), dim3(256), lds, st,
+                           reinterpret_cast<const cpx *>(in), reinterpret_cast<cpx *>(out), tw, inverse);
+    })
+    HIP_TRY(hipGetLastError());
+    return MP_OK;
 }
 
 int mp_scatter_f32(const int64_t *atom, const int64_t *batch, const int64_t *lag, const float *gain,

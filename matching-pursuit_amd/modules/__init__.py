@@ -13,3 +13,4 @@ from .matchingpursuit import (  # noqa: F401
     build_scatter_segments, dictionary_learning_step, flatten_atom_dict, sparse_coding_loss,
     sparse_feature_map, SparseCodingLoss)
 from .iterative import iterative_loss, sort_channels_descending_norm  # noqa: F401
+from .sparse import soft_dirac, sparsify2  # noqa: F401

@@ -25,7 +25,7 @@ MP_FLAG_NO_STAGGER = 16
 EXPORTS = (
     "mp_version", "mp_last_error", "mp_workspace_bytes", "mp_unit_norm_f32", "mp_encode_f32",
     "mp_feature_map_f32", "mp_scatter_f32", "mp_scatter_rows_f32", "mp_gather_sum_f32",
-    "mp_profile_enable", "mp_profile_read",
+    "mp_profile_enable", "mp_profile_read", "mp_fft_c2c_f32",
 )
 
 _lib = None
@@ -56,6 +56,7 @@ def lib():
         L.mp_scatter_f32.argtypes = [vp, vp, vp, vp, i64, vp, i64, i64, vp, i64, i64, vp]
         L.mp_scatter_rows_f32.argtypes = [vp, vp, vp, i64, i64, vp, i64, i64, vp]
         L.mp_gather_sum_f32.argtypes = [vp, i64, i64, vp, vp, i64, i64, vp, vp]
+        L.mp_fft_c2c_f32.argtypes = [vp, vp, ctypes.c_int, i64, ctypes.c_int, vp, vp]
         for name in EXPORTS:
             getattr(L, name)
         _lib = L
@@ -162,6 +163,23 @@ def feature_map(residual, dict_unit):
     _check(rc, "mp_feature_map_f32")
     ws.record_stream(torch.cuda.current_stream(dev))
     return fm
+
+
+def fft_c2c(x, inverse=False):
+    """Batched complex FFT test hook: x complex64 [batch, 2^k] on the device -> same shape, unscaled."""
+    _require_cuda(x)
+    assert x.dtype == torch.complex64 and x.dim() == 2 and x.is_contiguous()
+    batch, M = x.shape
+    lg = M.bit_length() - 1
+    assert 1 << lg == M
+    out = torch.empty_like(x)
+    ws = torch.empty(8 * M, dtype=torch.uint8, device=x.device)
+    xr, outr = torch.view_as_real(x), torch.view_as_real(out)
+    with torch.cuda.device(x.device):
+        rc = lib().mp_fft_c2c_f32(_ptr(xr), _ptr(outr), lg, batch, 1 if inverse else 0, _ptr(ws), _stream(x))
+    _check(rc, "mp_fft_c2c_f32")
+    ws.record_stream(torch.cuda.current_stream(x.device))
+    return out
 
 
 def _i64(t, dev):

@@ -192,6 +192,20 @@ def main():
     np.savez_compressed(os.path.join(HERE, "iterative_loss.npz"), target=target, channels=chans,
                         sorted_channels=srt, stft_target=tr, **outs)
 
+    # soft_dirac / sparsify2 (modules/sparse.py:29-89): forward values and the straight-through gradient
+    sparse_mod = importlib.import_module("modules.sparse")
+    rng = np.random.Generator(np.random.PCG64(1010))
+    xs = rng.standard_normal((3, 40)).astype(np.float32)
+    wts = rng.standard_normal((3, 40)).astype(np.float32)
+    xt = torch.from_numpy(xs).requires_grad_(True)
+    y = sparse_mod.soft_dirac(xt)
+    (y * torch.from_numpy(wts)).sum().backward()
+    x3 = rng.standard_normal((2, 6, 50)).astype(np.float32)
+    sp, packed, onehot = sparse_mod.sparsify2(torch.from_numpy(x3), n_to_keep=4)
+    np.savez_compressed(os.path.join(HERE, "sparse_helpers.npz"), x=xs, w=wts, soft_dirac=y.detach().numpy(),
+                        soft_dirac_grad=xt.grad.numpy(), x3=x3, sparse=sp.numpy(), packed=packed.numpy(),
+                        one_hot=onehot.numpy())
+
     print("fixture report (name, min relative top-2 gap, residual dB, direct==fft picks):")
     for r in report:
         print("  ", r)

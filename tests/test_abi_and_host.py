@@ -113,3 +113,17 @@ def test_shard_range_partitions():
             assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
             sizes = [b - a for a, b in spans]
             assert max(sizes) - min(sizes) <= 1
+
+
+def test_sparse_helpers_match_reference_golden(golden_dir):
+    from mpcore import sparse as mps
+    z = np.load(os.path.join(golden_dir, "sparse_helpers.npz"))
+    x = torch.from_numpy(z["x"]).requires_grad_(True)
+    y = mps.soft_dirac(x)
+    assert np.abs(y.detach().numpy() - z["soft_dirac"]).max() <= 2e-7
+    (y * torch.from_numpy(z["w"])).sum().backward()
+    assert np.abs(x.grad.numpy() - z["soft_dirac_grad"]).max() <= 1e-6
+    sp, packed, onehot = mps.sparsify2(torch.from_numpy(z["x3"]), n_to_keep=4)
+    assert np.array_equal(sp.numpy(), z["sparse"])
+    assert np.array_equal(packed.numpy(), z["packed"])
+    assert np.array_equal(onehot.numpy(), z["one_hot"])

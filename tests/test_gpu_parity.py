@@ -25,6 +25,8 @@ PATHS = [
     ("direct_nodma", nat.MP_PATH_DIRECT, nat.MP_FLAG_NO_DMA),
     ("direct_ta64", nat.MP_PATH_DIRECT, nat.MP_FLAG_TA64),
     ("incremental", nat.MP_PATH_INCREMENTAL, 0),
+    ("fft", nat.MP_PATH_FFT, 0),
+    ("fft_nodma", nat.MP_PATH_FFT, nat.MP_FLAG_NO_DMA),
     ("incremental_nonpersistent", nat.MP_PATH_INCREMENTAL, nat.MP_FLAG_NO_PERSISTENT),
     ("direct_nonpersistent_nodma", nat.MP_PATH_DIRECT, nat.MP_FLAG_NO_PERSISTENT | nat.MP_FLAG_NO_DMA),
     ("incremental_ta64_nodma", nat.MP_PATH_INCREMENTAL, nat.MP_FLAG_TA64 | nat.MP_FLAG_NO_DMA),
@@ -168,9 +170,41 @@ def test_bad_arguments_fail_loudly():
     with pytest.raises(nat.NativeError):
         nat.encode(torch.zeros(1, 64), du, 1)  # CPU tensor
     with pytest.raises(nat.NativeError):
-        nat.encode(torch.zeros(1, 64, device=DEV), du, 1, path=nat.MP_PATH_FFT)
-    with pytest.raises(nat.NativeError):
         nat.encode(torch.zeros(1, 64, device=DEV), du, 1, path=77)
+    with pytest.raises(nat.NativeError):  # one transform must fit LDS: atoms > 5398 samples
+        nat.encode(torch.zeros(1, 8000, device=DEV), torch.rand(2, 6000, device=DEV), 1, path=nat.MP_PATH_FFT)
+
+
+@pytest.mark.parametrize("log2_m", [8, 9, 10, 11, 12, 13, 14])
+def test_fft_transform_matches_numpy(log2_m):
+    """The radix-4 Stockham transform MP_PATH_FFT is built on, against numpy's fp64 FFT."""
+    M = 1 << log2_m
+    rng = np.random.default_rng(log2_m)
+    x = (rng.standard_normal((3, M)) + 1j * rng.standard_normal((3, M))).astype(np.complex64)
+    xd = torch.from_numpy(x).to(DEV)
+    ref = np.fft.fft(x.astype(np.complex128), axis=-1)
+    refi = np.fft.ifft(x.astype(np.complex128), axis=-1) * M
+    scale = np.abs(ref).max()
+    assert np.abs(nat.fft_c2c(xd).cpu().numpy() - ref).max() <= 2e-6 * scale
+    assert np.abs(nat.fft_c2c(xd, inverse=True).cpu().numpy() - refi).max() <= 2e-6 * scale
+
+
+def test_fft_path_all_zero_and_flat_inputs(oracle):
+    """Degenerate screens: a window of zeros has eps = 0 (keys exact, no refinement); a constant signal
+    makes many near-equal cells -- the result is either exact or loudly marked (gain = NaN)."""
+    du = oracle.unit_norm(synth.make_dictionary(8, 16, seed=3))
+    z = np.zeros((1, 300), dtype=np.float32)
+    atom, lag, gain, res = _gpu_encode(z, du, 2, nat.MP_PATH_FFT, 0)
+    assert (atom == 0).all() and (lag == 0).all() and (gain == 0).all()
+    flat = np.ones((2, 3000), dtype=np.float32)
+    want = oracle.encode(flat, du, 3)
+    atom, lag, gain, res = _gpu_encode(flat, du, 3, nat.MP_PATH_FFT, 0)
+    for b in range(2):
+        if np.isnan(gain[b]).any():
+            assert np.isnan(gain[b]).all()  # overflow is marked on the whole segment
+        else:
+            assert np.array_equal(atom[b], want["atom"][b]) and np.array_equal(lag[b], want["lag"][b])
+            assert np.array_equal(gain[b], want["gain"][b])
 
 
 # ---- BASELINE.json configs[1] shape: properties that do not need the (slow) oracle ---------------
@@ -188,9 +222,10 @@ def test_c2_incremental_equals_direct_bitwise(c2_inputs):
     inc = nat.encode(x, du, K, path=nat.MP_PATH_INCREMENTAL)
     full = nat.encode(x, du, K, path=nat.MP_PATH_DIRECT)
     ta32 = nat.encode(x, du, K, path=nat.MP_PATH_INCREMENTAL, flags=nat.MP_FLAG_TA64)
+    fft = nat.encode(x, du, K, path=nat.MP_PATH_FFT)
     torch.cuda.synchronize()
-    for p, q, r in zip(inc, full, ta32):
-        assert torch.equal(p, q) and torch.equal(p, r)
+    for p, q, r, s in zip(inc, full, ta32, fft):
+        assert torch.equal(p, q) and torch.equal(p, r) and torch.equal(p, s)
 
 
 def test_c2_roundtrip_and_monotone_energy(c2_inputs):
@@ -215,6 +250,27 @@ def test_c2_roundtrip_and_monotone_energy(c2_inputs):
     assert ((e0 - e1) >= 0.99 * removed).all()
     # the first event of a segment is its largest
     assert (gain[:, 0:1] >= gain - 1e-6).all()
+
+
+def test_c4_shape_paths_agree_and_roundtrip():
+    """BASELINE configs[3] shape (4096 x 2048 dictionary, 131072-sample segments), small batch:
+    FFT screen+refine == direct fma-chain kernels bit for bit; decode(events) + residual == signal."""
+    A, L, N, B, K = 4096, 2048, 131072, 2, 4
+    d = torch.from_numpy(synth.make_dictionary(A, L, seed=4000)).to(DEV)
+    x = torch.from_numpy(synth.make_segments(B, N, d.cpu().numpy(), n_events=24, seed=4001)).to(DEV)
+    du = nat.unit_norm(d)
+    fft = nat.encode(x, du, K, path=nat.MP_PATH_FFT)
+    inc = nat.encode(x, du, K, path=nat.MP_PATH_INCREMENTAL)
+    full = nat.encode(x[:1], du, 2, path=nat.MP_PATH_DIRECT)
+    torch.cuda.synchronize()
+    assert not torch.isnan(fft[2]).any()
+    for p, q in zip(fft, inc):
+        assert torch.equal(p, q)
+    assert torch.equal(full[0], inc[0][:1, :2]) and torch.equal(full[2], inc[2][:1, :2])
+    atom, lag, gain, residual = fft
+    recon = torch.zeros_like(x)
+    nat.scatter(atom, torch.arange(B, device=DEV)[:, None].expand(B, K), lag, gain, du, recon)
+    assert (recon + residual - x).abs().max().item() <= 4e-5 * x.abs().max().item()
 
 
 def test_c2_golden_shape_vs_oracle_bitwise(oracle, c2_inputs):
