@@ -105,26 +105,13 @@ def roofline_from(prof, flops_one_encode, steps):
     }
 
 
-def host_cpu_share():
-    """CPUs this process may actually use: affinity mask, capped by the cgroup CPU quota (the GPU
-    box exposes 256 logical CPUs but grants a 16-CPU share)."""
-    n = len(os.sched_getaffinity(0))
-    try:
-        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
-        if quota != "max":
-            n = min(n, max(1, int(int(quota) / int(period))))
-    except (OSError, ValueError):
-        pass
-    return n
-
-
 def cpu_baseline(d, x_host, gpu_sample):
     """The oracle (oracle/mp_oracle.c, the CPU restatement of the reference) on this host's cores,
     on a bounded sample of the same workload; also the in-run parity check."""
     sys.path.insert(0, os.path.join(REPO, "oracle"))
     import mp_oracle
     mp_oracle.build()
-    threads = host_cpu_share()
+    threads = mp_oracle.cpu_share()
     mp_oracle.set_num_threads(threads)
     du = mp_oracle.unit_norm(d)
     mp_oracle.encode(x_host[:1], du, 1)  # warm the thread pool

@@ -50,6 +50,12 @@ extern "C" {
 #define MP_FLAG_TA32 2   /* 32-atom workgroup tiles (64 KiB of LDS, two workgroups per CU): default */
 #define MP_FLAG_TA64 4   /* 64-atom workgroup tiles (128 KiB of LDS, one workgroup per CU)         */
 #define MP_FLAG_NO_STAGGER 16 /* do not delay odd wave slots by half a cell on incremental launches */
+#define MP_FLAG_REFINE_MFMA 32 /* MP_PATH_FFT: refine contender cells on the MFMA cell code instead of VALU chains */
+#define MP_FLAG_FFT_SIMPLE 64 /* MP_PATH_FFT: plain radix-4 screen kernel instead of the register radix-16 one */
+#define MP_FLAG_FFT_PREFETCH 128 /* MP_PATH_FFT: register-prefetch the next pair's spectrum (more VGPRs) */
+#define MP_FLAG_FFT_WAVE 256 /* MP_PATH_FFT: one-wavefront-per-transform screen (M = 1024 / 2048 only)          */
+#define MP_FLAG_FFT_UNFUSED 512 /* MP_PATH_FFT: select-A / refine / select-B always as three kernels            */
+#define MP_FLAG_FFT_FUSED 1024  /* MP_PATH_FFT: ... always as one kernel (default: by cells per segment)        */
 #define MP_FLAG_NO_PERSISTENT 8 /* one workgroup per 4 cells instead of machine-sized persistent grid */
 
 int mp_version(void);

@@ -79,6 +79,7 @@ typedef unsigned long long u64;
 constexpr int LAGS_PER_WAVE = 64;   // one cell = TA atoms x 64 lags, owned by one wavefront
 constexpr int WAVES = 4;            // wavefronts per workgroup
 constexpr int KC_MAX = 512;         // atom samples staged in LDS per chunk
+constexpr int MAXCONT = 32;         // FFT path: inexact contender cells per segment per iteration
 
 __host__ __device__ inline int64_t round_up(int64_t x, int64_t m) { return (x + m - 1) / m * m; }
 
@@ -580,11 +581,21 @@ __global__ void correlate_naive_kernel(const float *__restrict__ res, const floa
 __global__ __launch_bounds__(256) void select_subtract_kernel(
     const u64 *__restrict__ keys, int64_t n_keys, float *__restrict__ res, const float *__restrict__ du,
     int *__restrict__ dirty, int64_t *__restrict__ out_atom, int64_t *__restrict__ out_lag,
-    float *__restrict__ out_gain, int64_t N, int64_t L, int64_t Ns, int NBLK, int K, int k) {
+    float *__restrict__ out_gain, int64_t N, int64_t L, int64_t Ns, int NBLK, int K, int k,
+    const int *__restrict__ cont, const int *__restrict__ ncont, u64 *__restrict__ keys_wb,
+    float *__restrict__ ceps_wb, int64_t n_cells) {
     __shared__ u64 s_key[4];
     const int b = blockIdx.x;
     const int tid = threadIdx.x;
     const u64 *kb = keys + (int64_t)b * n_keys;
+    if (cont) {  // FFT path: the refined cells' exact keys replace the screened ones (eps = 0)
+        const int nc = ncont[b];
+        if (tid < nc) {
+            const int64_t cidx = (int64_t)b * n_cells + cont[b * MAXCONT + tid];
+            keys_wb[cidx] = kb[tid];
+            ceps_wb[cidx] = 0.0f;
+        }
+    }
     u64 best = 0;
     for (int64_t e = tid; e < n_keys; e += 256) {
         u64 v = kb[e];
@@ -612,6 +623,15 @@ __global__ __launch_bounds__(256) void select_subtract_kernel(
             dirty[2 * b] = fb;
             dirty[2 * b + 1] = lb - fb + 1;
         }
+    }
+    if (keys_wb) {  // FFT path: the screen merges with atomicMax, so the cells it will redo start from 0
+        int64_t lo = lag - L + 1; if (lo < 0) lo = 0;
+        int64_t hi = lag + L - 1; if (hi > N - 1) hi = N - 1;
+        const int fb = (int)(lo / LAGS_PER_WAVE), lb = (int)(hi / LAGS_PER_WAVE);
+        const int nat = (int)(n_cells / NBLK);
+        u64 *kz = keys_wb + (int64_t)b * n_cells + (int64_t)fb * nat;
+        const int nz = (lb - fb + 1) * nat;
+        for (int e = tid; e < nz; e += 256) kz[e] = 0ull;
     }
     const int64_t len = (N - lag) < L ? (N - lag) : L;
     float *r = res + (int64_t)b * Ns + lag;
@@ -893,6 +913,7 @@ int fft_lds_attr(K kern, size_t bytes) {
     return MP_OK;
 }
 
+int screen_pps_override = 0;  // tuning hook (mp_tune)
 constexpr float FFT_TAU = 1.0e-4f;  // screen error bound per unit of window norm
 
 int encode_fft(const Geom &g, const Workspace &w, const float *du, int K, int flags, int64_t *out_atom,
@@ -908,6 +929,7 @@ int encode_fft(const Geom &g, const Workspace &w, const float *du, int K, int fl
     hipLaunchKernelGGL(fft_twiddle_kernel, dim3((f.M + 255) / 256), dim3(256), 0, st, w.tw, f.M);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemsetAsync(w.overflow, 0, (size_t)g.B * sizeof(int), st));
+    HIP_TRY(hipMemsetAsync(w.keys, 0, (size_t)g.B * n_cells * sizeof(u64), st));
     MP_FFT_DISPATCH(f.logM, {
         if ((rc = fft_lds_attr(fft_dict_kernel<LG>, lds))) return rc;
         if ((rc = fft_lds_attr(fft_window_kernel<LG>, lds))) return rc;
@@ -923,30 +945,80 @@ int encode_fft(const Geom &g, const Workspace &w, const float *du, int K, int fl
     for (int k = 0; k < K; ++k) {
         const int *dirty = k == 0 ? nullptr : w.dirty;
         const int nw = k == 0 ? f.NW : 1;
-        g_prof.begin(k == 0 ? PROF_CORR_FULL : PROF_CORR_INC, st);
+        g_prof.begin(PROF_SELECT, st);
         MP_FFT_DISPATCH(f.logM, {
             hipLaunchKernelGGL(fft_window_kernel<LG>, dim3(nw, (unsigned)g.B), dim3(256), lds, st, w.res, g.Ns,
                                dirty, w.tw, w.xspec, w.wnorm, f.V, f.NW);
-            hipLaunchKernelGGL(fft_correlate_kernel<LG>, dim3(nw, g.NAT, (unsigned)g.B), dim3(256), lds, st,
-                               w.xspec, w.pspec, w.tw, dirty, w.wnorm, w.keys, w.ceps, g.N, g.A, g.NBLK, g.NAT,
-                               f.V, f.NW, FFT_TAU);
+        })
+        g_prof.end(st);
+        g_prof.begin(k == 0 ? PROF_CORR_FULL : PROF_CORR_INC, st);
+        MP_FFT_DISPATCH(f.logM, {
+            if ((LG == 10 || LG == 11) && (flags & MP_FLAG_FFT_WAVE) && !(flags & MP_FLAG_FFT_SIMPLE)) {
+                constexpr int LW = (LG == 10 || LG == 11) ? LG : 10;  // (dead branch for other LG)
+                int pps = 16;
+                const int64_t tasks = (int64_t)nw * g.NAT * g.B;
+                while (pps > 1 && tasks * (16 / pps) < 32 * (int64_t)num_cus()) pps >>= 1;
+                if (screen_pps_override > 0 && 16 % screen_pps_override == 0) pps = screen_pps_override;
+                const size_t lds_s = ((size_t)(1 << LW) + (1 << LW) / 64 + 64) * sizeof(cpx);
+                hipLaunchKernelGGL(fft_screen_wave_kernel<LW>, dim3(nw * (16 / pps), g.NAT, (unsigned)g.B), dim3(64),
+                                   lds_s, st, w.xspec, w.pspec, w.tw, dirty, w.wnorm, w.keys, w.ceps, g.N, g.A,
+                                   g.NBLK, g.NAT, f.V, f.NW, FFT_TAU, pps);
+            } else if (LG >= 10 && !(flags & MP_FLAG_FFT_SIMPLE)) {
+                constexpr int LS = LG >= 10 ? LG : 10;  // (the branch is dead for smaller LG)
+                using C = ScreenCfg<LS>;
+                // pairs per slot: fewest workgroups that still oversubscribe the machine ~8x
+                int pps = 16 / C::SLOTS;
+                const int64_t tasks = (int64_t)nw * g.NAT * g.B;
+                while (pps > 1 && tasks * (16 / (C::SLOTS * pps)) < 8 * (int64_t)num_cus()) pps >>= 1;
+                if (screen_pps_override > 0 && 16 % (C::SLOTS * screen_pps_override) == 0) pps = screen_pps_override;
+                const size_t lds_s = ((size_t)C::SLOTS * C::M + C::M / 64 + 64) * sizeof(cpx);
+                if (flags & MP_FLAG_FFT_PREFETCH) {
+                    if ((rc = fft_lds_attr(fft_screen_kernel<LS, true>, lds_s))) return rc;
+                    hipLaunchKernelGGL((fft_screen_kernel<LS, true>), dim3(nw * (16 / (C::SLOTS * pps)), g.NAT, (unsigned)g.B),
+                                       dim3(C::WG), lds_s, st, w.xspec, w.pspec, w.tw, dirty, w.wnorm, w.keys, w.ceps,
+                                       g.N, g.A, g.NBLK, g.NAT, f.V, f.NW, FFT_TAU, pps);
+                } else {
+                    if ((rc = fft_lds_attr(fft_screen_kernel<LS, false>, lds_s))) return rc;
+                    hipLaunchKernelGGL((fft_screen_kernel<LS, false>), dim3(nw * (16 / (C::SLOTS * pps)), g.NAT, (unsigned)g.B),
+                                       dim3(C::WG), lds_s, st, w.xspec, w.pspec, w.tw, dirty, w.wnorm, w.keys, w.ceps,
+                                       g.N, g.A, g.NBLK, g.NAT, f.V, f.NW, FFT_TAU, pps);
+                }
+            } else {
+                hipLaunchKernelGGL(fft_correlate_kernel<LG>, dim3(nw, g.NAT, (unsigned)g.B), dim3(256), lds, st,
+                                   w.xspec, w.pspec, w.tw, dirty, w.wnorm, w.keys, w.ceps, g.N, g.A, g.NBLK,
+                                   g.NAT, f.V, f.NW, FFT_TAU);
+            }
         })
         g_prof.end(st);
         HIP_TRY(hipGetLastError());
         g_prof.begin(PROF_SELECT, st);
-        hipLaunchKernelGGL(fft_select_a_kernel, dim3((unsigned)g.B), dim3(256), 0, st, w.keys, w.ceps, n_cells,
-                           w.cont, w.ncont, w.ekeys, w.overflow);
-        if (dma)
-            hipLaunchKernelGGL(fft_refine_kernel<true>, dim3(MAXCONT, (unsigned)g.B), dim3(256), lds_ref, st, w.res,
-                               w.img, w.cont, w.ncont, w.keys, w.ceps, w.ekeys, g.N, g.A, g.Ns, g.NBLK, g.NAT,
-                               g.KC, g.NCH);
-        else
-            hipLaunchKernelGGL(fft_refine_kernel<false>, dim3(MAXCONT, (unsigned)g.B), dim3(256), lds_ref, st, w.res,
-                               w.img, w.cont, w.ncont, w.keys, w.ceps, w.ekeys, g.N, g.A, g.Ns, g.NBLK, g.NAT,
-                               g.KC, g.NCH);
-        hipLaunchKernelGGL(select_subtract_kernel, dim3((unsigned)g.B), dim3(256), 0, st, w.ekeys,
-                           (int64_t)(MAXCONT + 1), w.res, du, w.dirty, out_atom, out_lag, out_gain, g.N, g.L,
-                           g.Ns, g.NBLK, K, k);
+        // one fused kernel per iteration pays off when a segment has many cells to scan (measured:
+        // config-4 shape 190 vs 315 us; headline shape 50 vs 35 us)
+        const bool fused = (flags & MP_FLAG_FFT_FUSED) || (n_cells >= 65536 && !(flags & MP_FLAG_FFT_UNFUSED));
+        if (fused && !(flags & MP_FLAG_REFINE_MFMA)) {
+            const size_t lds_f = (size_t)(round_up(g.L, 64) + 128) * sizeof(float);
+            hipLaunchKernelGGL(fft_select_fused_kernel, dim3((unsigned)g.B), dim3(1024), lds_f, st, w.keys, w.ceps,
+                               n_cells, w.res, du, w.dirty, w.overflow, out_atom, out_lag, out_gain, g.N, g.A, g.L,
+                               g.Ns, g.NBLK, g.NAT, K, k);
+        } else {
+            hipLaunchKernelGGL(fft_select_a_kernel, dim3((unsigned)g.B), dim3(1024), 0, st, w.keys, w.ceps, n_cells,
+                               w.cont, w.ncont, w.ekeys, w.overflow);
+            if (flags & MP_FLAG_REFINE_MFMA) {
+                if (dma)
+                    hipLaunchKernelGGL(fft_refine_kernel<true>, dim3((unsigned)g.B, 4), dim3(256), lds_ref, st, w.res,
+                                       w.img, w.cont, w.ncont, w.ekeys, g.N, g.A, g.Ns, g.NBLK, g.NAT, g.KC, g.NCH);
+                else
+                    hipLaunchKernelGGL(fft_refine_kernel<false>, dim3((unsigned)g.B, 4), dim3(256), lds_ref, st, w.res,
+                                       w.img, w.cont, w.ncont, w.ekeys, g.N, g.A, g.Ns, g.NBLK, g.NAT, g.KC, g.NCH);
+            } else {
+                const size_t lds_win = (size_t)(round_up(g.L, 64) + 128) * sizeof(float);
+                hipLaunchKernelGGL(fft_refine_valu_kernel, dim3(8, 1, (unsigned)g.B), dim3(256), lds_win, st, w.res, du,
+                                   w.cont, w.ncont, w.ekeys, g.N, g.A, g.L, g.Ns, g.NAT);
+            }
+            hipLaunchKernelGGL(select_subtract_kernel, dim3((unsigned)g.B), dim3(256), 0, st, w.ekeys,
+                               (int64_t)(MAXCONT + 1), w.res, du, w.dirty, out_atom, out_lag, out_gain, g.N, g.L,
+                               g.Ns, g.NBLK, K, k, w.cont, w.ncont, w.keys, w.ceps, n_cells);
+        }
         g_prof.end(st);
         HIP_TRY(hipGetLastError());
     }
@@ -1057,7 +1129,8 @@ int mp_encode_f32(const float *signal, int64_t B, int64_t N, const float *dict_u
         g_prof.begin(PROF_SELECT, st);
         hipLaunchKernelGGL(select_subtract_kernel, dim3((unsigned)B), dim3(256), 0, st, w.keys, n_keys,
                            w.res, dict_unit, incremental ? w.dirty : nullptr, out_atom, out_lag, out_gain,
-                           N, L, g.Ns, g.NBLK, K, k);
+                           N, L, g.Ns, g.NBLK, K, k, (const int *)nullptr, (const int *)nullptr, (u64 *)nullptr,
+                           (float *)nullptr, (int64_t)0);
         g_prof.end(st);
         HIP_TRY(hipGetLastError());
     }

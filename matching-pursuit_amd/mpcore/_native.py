@@ -21,6 +21,12 @@ MP_FLAG_TA32 = 2
 MP_FLAG_TA64 = 4
 MP_FLAG_NO_PERSISTENT = 8
 MP_FLAG_NO_STAGGER = 16
+MP_FLAG_REFINE_MFMA = 32
+MP_FLAG_FFT_SIMPLE = 64
+MP_FLAG_FFT_PREFETCH = 128
+MP_FLAG_FFT_WAVE = 256
+MP_FLAG_FFT_UNFUSED = 512
+MP_FLAG_FFT_FUSED = 1024
 
 EXPORTS = (
     "mp_version", "mp_last_error", "mp_workspace_bytes", "mp_unit_norm_f32", "mp_encode_f32",

@@ -31,6 +31,19 @@ def build(force=False):
     return _LIB_PATH
 
 
+def cpu_share():
+    """CPUs this process may use: the affinity mask capped by the cgroup quota (a GPU box shows 256
+    logical CPUs but grants 16; 256 OpenMP threads on 16 cores run several times slower)."""
+    n = len(os.sched_getaffinity(0))
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
 def lib():
     global _lib
     if _lib is None:
@@ -38,6 +51,7 @@ def lib():
             build()
         _lib = ctypes.CDLL(_LIB_PATH)
         _lib.mpo_num_threads.restype = ctypes.c_int
+        _lib.mpo_set_num_threads(ctypes.c_int(cpu_share()))
     return _lib
 
 

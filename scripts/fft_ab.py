@@ -1,0 +1,37 @@
+#!/usr/bin/env python3
+"""Interleaved A/B of MP_PATH_FFT variants (and the incremental path) at the headline shape."""
+import os, sys, time
+import numpy as np, torch
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(REPO, "matching-pursuit_amd"))
+from mpcore import _native as nat
+from mpcore import synth
+shape = sys.argv[1] if len(sys.argv) > 1 else "c2"
+rounds = int(sys.argv[2]) if len(sys.argv) > 2 else 5
+A, L, N, B, K = {"c2": (512, 512, 32768, 64, 64), "c4": (4096, 2048, 131072, 16, 16)}[shape]
+variants = [("fft", 1, 0), ("fft_unfused", 1, 512), ("fft_fused", 1, 1024), ("fft_refine_mfma", 1, 32)]
+if shape == "c2":
+    variants.append(("incremental", 2, 0))
+d = synth.make_dictionary(A, L, seed=1000)
+x = torch.from_numpy(synth.make_segments(B, N, d, n_events=min(3 * K, 192), seed=1002)).cuda()
+du = nat.unit_norm(torch.from_numpy(d).cuda())
+ref = None
+times = {v[0]: [] for v in variants}
+profs = {}
+nat.profile_enable(True)
+for r in range(rounds + 1):
+    for name, path, flags in variants:
+        torch.cuda.synchronize(); nat.profile_read()
+        t0 = time.perf_counter()
+        out = nat.encode(x, du, K, path=path, flags=flags, want_residual=False)
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) * 1e3
+        p = nat.profile_read()
+        if r > 0:
+            times[name].append(dt); profs[name] = p
+        if ref is None: ref = out
+        elif r == 0:
+            print(name, "== first variant:", all(torch.equal(a, b) for a, b in zip(out[:3], ref[:3])), "nan", torch.isnan(out[2]).any().item(), flush=True)
+for name, path, flags in variants:
+    t = np.array(times[name]); p = profs[name]
+    print(f"{name:18s} median {np.median(t):8.3f} ms min {t.min():8.3f} -> {B*K/np.median(t)*1e3:9.0f} seg-it/s | full {p['corr_full'][0]/max(p['corr_full'][1],1):7.3f} ms inc {p['corr_inc'][0]/max(p['corr_inc'][1],1)*1e3:7.1f} us select {p['select'][0]/max(p['select'][1],1)*1e3:6.1f} us", flush=True)

@@ -26,7 +26,13 @@ PATHS = [
     ("direct_ta64", nat.MP_PATH_DIRECT, nat.MP_FLAG_TA64),
     ("incremental", nat.MP_PATH_INCREMENTAL, 0),
     ("fft", nat.MP_PATH_FFT, 0),
-    ("fft_nodma", nat.MP_PATH_FFT, nat.MP_FLAG_NO_DMA),
+    ("fft_refine_mfma", nat.MP_PATH_FFT, nat.MP_FLAG_REFINE_MFMA),
+    ("fft_refine_mfma_nodma", nat.MP_PATH_FFT, nat.MP_FLAG_REFINE_MFMA | nat.MP_FLAG_NO_DMA),
+    ("fft_unfused", nat.MP_PATH_FFT, nat.MP_FLAG_FFT_UNFUSED),
+    ("fft_fused", nat.MP_PATH_FFT, nat.MP_FLAG_FFT_FUSED),
+    ("fft_wave", nat.MP_PATH_FFT, nat.MP_FLAG_FFT_WAVE),
+    ("fft_simple", nat.MP_PATH_FFT, nat.MP_FLAG_FFT_SIMPLE),
+    ("fft_prefetch", nat.MP_PATH_FFT, nat.MP_FLAG_FFT_PREFETCH),
     ("incremental_nonpersistent", nat.MP_PATH_INCREMENTAL, nat.MP_FLAG_NO_PERSISTENT),
     ("direct_nonpersistent_nodma", nat.MP_PATH_DIRECT, nat.MP_FLAG_NO_PERSISTENT | nat.MP_FLAG_NO_DMA),
     ("incremental_ta64_nodma", nat.MP_PATH_INCREMENTAL, nat.MP_FLAG_TA64 | nat.MP_FLAG_NO_DMA),
