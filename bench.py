@@ -10,9 +10,11 @@ rank per GPU) every rank encodes its own 64 segments (configs[2] at N = 8: 512 s
 collective on the data path, weak scaling; rank 0 prints ONE JSON line.
 
 value = segment-iterations/s over all ranks, inputs resident in HBM, timed between
-barrier+synchronize pairs, max over ranks.  `roofline` is for the dominant kernel (the MFMA
-correlate kernel) from HIP events recorded inside the timed region on the launch stream;
-`cpu_baseline` is the CPU oracle timed on this host (rank 0, N = 1 only).
+barrier+synchronize pairs, max over ranks, on the library's default schedule (MP_PATH_FFT: FFT
+screen + exact refinement; events bit-identical to the direct paths, re-checked every run).
+`roofline` is for that schedule's dominant kernel from HIP events recorded inside the timed region on
+the launch stream; `variants` carries the two direct-correlation (MFMA) schedules with their own
+rooflines; `cpu_baseline` is the CPU oracle timed on this host (rank 0, N = 1 only).
 """
 import argparse
 import json
@@ -32,6 +34,31 @@ from mpcore import synth  # noqa: E402
 
 A, L, N, B_PER_GPU, K_ITERS = 512, 512, 32768, 64, 64
 PEAK_MFMA_F32_TFLOPS = 157.3  # MI355X dense fp32 matrix peak (MI355X_MICROARCH.md)
+PEAK_HBM_GBS = 8000.0         # MI355X HBM3E peak (MI355X_MICROARCH.md)
+PATHS = {"fft": nat.MP_PATH_FFT, "incremental": nat.MP_PATH_INCREMENTAL, "direct": nat.MP_PATH_DIRECT}
+
+
+def fft_geometry():
+    """(M, V): transform size and valid lags per transform, as csrc/mpfft.inc::make_fft_geom."""
+    M = 256
+    while M < 3 * L + 190:
+        M *= 2
+    return M, (M - L + 1) // 64 * 64
+
+
+def algorithmic_bytes_fft(n_segments, steps_k):
+    """Bytes the FFT screen kernel must read per encode, by its own algorithm: per (segment, window)
+    the window spectrum (8 M bytes) and one pair spectrum per two atoms (A/2 * 8 M bytes), plus one
+    8-byte key and 4-byte bound written per cell.  Full pass: ceil(N / V) windows per segment;
+    every later step: one window per segment."""
+    M, V = fft_geometry()
+    per_window = 8.0 * M * (A // 2 + 1)
+    nw_full = -(-N // V)
+    cells_full = (N // 64) * (A // 32) * 12.0
+    cells_inc = ((2 * L - 2) // 64 + 2) * (A // 32) * 12.0
+    full = n_segments * (nw_full * per_window + cells_full)
+    inc = n_segments * (steps_k - 1) * (per_window + cells_inc)
+    return full + inc, full, inc
 
 
 def algorithmic_flops(lag, path):
@@ -67,8 +94,8 @@ def timed_encodes(x, du, steps, warmup, path, flags, group):
     return float(t.item()), out, nat.profile_read()
 
 
-def pmc_traffic():
-    """HBM bytes per launch of the correlate kernel from the newest committed PMC summary
+def pmc_traffic(kernel="correlate"):
+    """HBM bytes per launch of the named kernel from the newest committed PMC summary
     (profiles/rNN_summary.json: FETCH_SIZE x2 + WRITE_SIZE, separate rocprofv3 --pmc passes of this
     same command; counters cannot be read from inside the process).  None if there is none."""
     import glob
@@ -79,9 +106,37 @@ def pmc_traffic():
         except (OSError, ValueError):
             continue
         for k, v in d.items():
-            if k.startswith("hbm_traffic_bytes_per_launch_correlate"):
+            if k.startswith("hbm_traffic_bytes_per_launch_" + kernel):
                 return {"bytes_per_launch": v, "source": os.path.relpath(f, REPO)}
     return None
+
+
+def roofline_fft(prof, n_segments, steps):
+    """HBM-style roofline of fft_screen_kernel: algorithmic bytes (above) / summed launch durations."""
+    ms_full, n_full = prof["corr_full"]
+    ms_inc, n_inc = prof["corr_inc"]
+    launches = n_full + n_inc
+    if launches == 0:
+        return None
+    total, full, inc = algorithmic_bytes_fft(n_segments, K_ITERS)
+    sec = (ms_full + ms_inc) * 1e-3
+    achieved = total * steps / sec / 1e9
+    M, V = fft_geometry()
+    survey_bytes = (8.0 * ((N + L) // 2 + 1) * (A + 1) + 8.0 * N) * n_segments * K_ITERS  # SURVEY.md 8(d)
+    return {
+        "bound": "hbm", "achieved": round(achieved, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
+        "frac": round(achieved / PEAK_HBM_GBS, 4), "traffic": pmc_traffic("fft_screen"),
+        "kernel": "fft_screen_kernel<11,false> (radix-16 Stockham, packed fp32)",
+        "launches": launches, "avg_launch_ms": round((ms_full + ms_inc) / launches, 5),
+        "full_pass_launches": n_full, "full_pass_avg_ms": round(ms_full / max(n_full, 1), 5),
+        "incremental_launches": n_inc, "incremental_avg_ms": round(ms_inc / max(n_inc, 1), 5),
+        "other_kernels_avg_ms_per_step": round(prof["select"][0] / max(n_full + n_inc, 1), 5),
+        "algorithmic_mb_per_launch": round(total * steps / launches / 1e6, 2),
+        "note": "algorithmic bytes = spectra the kernel's own algorithm streams (mostly L2/Infinity-Cache "
+                "hits: the 4 MiB of pair spectra are shared by all segments); the kernel is packed-fp32 "
+                "VALU / LDS limited, see DESIGN.md",
+        "survey_8d_equivalent_gbs": round(survey_bytes * steps / sec / 1e9, 1),
+    }
 
 
 def roofline_from(prof, flops_one_encode, steps):
@@ -143,7 +198,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--path", default="incremental", choices=["incremental", "direct"])
+    ap.add_argument("--path", default="fft", choices=list(PATHS))
     ap.add_argument("--flags", type=int, default=0)
     ap.add_argument("--no-variants", action="store_true", help="skip the direct-path variant leg")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
@@ -172,12 +227,14 @@ def main():
     torch.cuda.synchronize()
 
     nat.profile_enable(True)
-    path = nat.MP_PATH_INCREMENTAL if args.path == "incremental" else nat.MP_PATH_DIRECT
+    path = PATHS[args.path]
     dt, out, prof = timed_encodes(x, du, args.steps, args.warmup, path, args.flags, group)
     atom, lag, gain, residual = [t.cpu().numpy() for t in out]
     seg_its = world * B_PER_GPU * K_ITERS * args.steps
-    flops = algorithmic_flops(lag, path)
-    roof = roofline_from(prof, flops, args.steps)
+    if path == nat.MP_PATH_FFT:
+        roof = roofline_fft(prof, B_PER_GPU, args.steps)
+    else:
+        roof = roofline_from(prof, algorithmic_flops(lag, path), args.steps)
     rdb = 20 * np.log10(np.linalg.norm(residual, axis=-1) / np.linalg.norm(x_host, axis=-1))
 
     line = {
@@ -200,18 +257,23 @@ def main():
 
     if rank == 0 and world == 1:
         if not args.no_variants:
-            other = nat.MP_PATH_DIRECT if path == nat.MP_PATH_INCREMENTAL else nat.MP_PATH_INCREMENTAL
-            name = "direct_full_recompute" if other == nat.MP_PATH_DIRECT else "incremental"
-            vsteps = max(1, min(args.steps, 2))
-            vdt, vout, vprof = timed_encodes(x, du, vsteps, 1, other, args.flags, group)
-            vlag = vout[1].cpu().numpy()
-            same = all(torch.equal(p, q) for p, q in zip(vout, out))
-            line["variants"] = {name: {
-                "value": round(B_PER_GPU * K_ITERS * vsteps / vdt, 2), "unit": "segment-iterations/s",
-                "ms_per_step": round(vdt / vsteps * 1e3, 4), "steps": vsteps,
-                "bit_identical_to_headline": bool(same),
-                "roofline": roofline_from(vprof, algorithmic_flops(vlag, other), vsteps),
-            }}
+            line["variants"] = {}
+            for name, other in (("incremental_direct_mfma", nat.MP_PATH_INCREMENTAL),
+                                ("direct_full_recompute_mfma", nat.MP_PATH_DIRECT),
+                                ("fft_screen_refine", nat.MP_PATH_FFT)):
+                if other == path:
+                    continue
+                vsteps = 1 if other == nat.MP_PATH_DIRECT else max(1, min(args.steps, 3))
+                vdt, vout, vprof = timed_encodes(x, du, vsteps, 1, other, args.flags, group)
+                vlag = vout[1].cpu().numpy()
+                same = all(torch.equal(p, q) for p, q in zip(vout, out))
+                vroof = (roofline_fft(vprof, B_PER_GPU, vsteps) if other == nat.MP_PATH_FFT
+                         else roofline_from(vprof, algorithmic_flops(vlag, other), vsteps))
+                line["variants"][name] = {
+                    "value": round(B_PER_GPU * K_ITERS * vsteps / vdt, 2), "unit": "segment-iterations/s",
+                    "ms_per_step": round(vdt / vsteps * 1e3, 4), "steps": vsteps,
+                    "bit_identical_to_headline": bool(same), "roofline": vroof,
+                }
         if not args.no_cpu:
             base, parity = cpu_baseline(d, x_host, (atom, lag, gain))
             line["cpu_baseline"] = base

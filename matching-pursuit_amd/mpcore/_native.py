@@ -121,6 +121,34 @@ def workspace_bytes(B, N, A, L, K, path):
     return int(n)
 
 
+FFT_MAX_ATOM = 5398  # longest atom whose 3L+190-point transform fits one workgroup's LDS
+
+
+def default_path(n_atom_samples):
+    """The fastest exact schedule: the FFT screen + exact refinement where a transform fits LDS,
+    the incremental direct (MFMA) schedule otherwise.  All paths select identical events."""
+    return MP_PATH_FFT if n_atom_samples <= FFT_MAX_ATOM else MP_PATH_INCREMENTAL
+
+
+def encode_checked(signal, dict_unit, n_steps, flags=0, want_residual=True):
+    """encode() on the default path, plus the one thing the asynchronous call cannot do itself: if a
+    segment's FFT screen overflowed (marked in-band with gain = NaN, see include/mpcore.h) that segment is
+    re-encoded on the incremental path.  Costs one host synchronisation."""
+    path = default_path(dict_unit.shape[1])
+    atom, lag, gain, residual = encode(signal, dict_unit, n_steps, path=path, flags=flags,
+                                       want_residual=want_residual)
+    if path == MP_PATH_FFT and gain.numel():
+        bad = torch.isnan(gain).any(dim=1)
+        if bool(bad.any()):
+            idx = torch.nonzero(bad).flatten()
+            a2, l2, g2, r2 = encode(signal[idx], dict_unit, n_steps, path=MP_PATH_INCREMENTAL, flags=flags,
+                                    want_residual=want_residual)
+            atom[idx], lag[idx], gain[idx] = a2, l2, g2
+            if want_residual:
+                residual[idx] = r2
+    return atom, lag, gain, residual
+
+
 def encode(signal, dict_unit, n_steps, path=MP_PATH_INCREMENTAL, flags=0, want_residual=True):
     """signal [B,N] f32 cuda, dict_unit [A,L] f32 cuda -> (atom[B,K] i64, lag[B,K] i64,
     gain[B,K] f32, residual[B,N] f32 | None), all on signal.device, asynchronous."""

@@ -114,14 +114,17 @@ def _make_events(atom, lag, gain, dict_unit, out_device):
 
 def encode_packed(signal, d, n_steps, path=None, flags=0):
     """The fast interface: signal [B,1,N] or [B,N], raw dictionary d [A,L] ->
-    dict(atom[B,K], lag[B,K], gain[B,K], residual[B,N], dict_unit[A,L]) on the compute device,
-    no host synchronisation, no Python objects per event."""
+    dict(atom[B,K], lag[B,K], gain[B,K], residual[B,N], dict_unit[A,L]) on the compute device, no
+    Python objects per event.  path=None: the default schedule with its overflow check (one host
+    sync); an explicit MP_PATH_* is fully asynchronous."""
     if signal.dim() == 3:
         signal = signal[:, 0, :]
     dev = _compute_device(signal)
     du = _native.unit_norm(d.to(dev))
-    p = _native.MP_PATH_INCREMENTAL if path is None else path
-    atom, lag, gain, residual = _native.encode(signal.to(dev), du, n_steps, path=p, flags=flags)
+    if path is None:
+        atom, lag, gain, residual = _native.encode_checked(signal.to(dev), du, n_steps, flags=flags)
+    else:
+        atom, lag, gain, residual = _native.encode(signal.to(dev), du, n_steps, path=path, flags=flags)
     return dict(atom=atom, lag=lag, gain=gain, residual=residual, dict_unit=du)
 
 
@@ -249,8 +252,7 @@ def sparse_code(
             signal.to(dev), d_unit, n_steps, approx if approximate else None, extract_atom_embedding,
             visit_key_point, local_contrast_norm, compute_feature_map)
     else:
-        atom, lag, gain, residual = _native.encode(signal.to(dev)[:, 0, :], d_unit, n_steps,
-                                                   path=_native.MP_PATH_INCREMENTAL)
+        atom, lag, gain, residual = _native.encode_checked(signal.to(dev)[:, 0, :], d_unit, n_steps)
         embeddings = None
 
     if extract_atom_embedding is not None:  # :332-333
@@ -394,7 +396,7 @@ def dictionary_learning_step(
                                                    approx if not (approx is None) else None, None, None,
                                                    local_constrast_norm, compute_feature_map)
     else:
-        atom, lag, gain, _ = _native.encode(sig, d_work, n_steps, want_residual=False)
+        atom, lag, gain, _ = _native.encode_checked(sig, d_work, n_steps, want_residual=False)
 
     K = atom.shape[1]
     # per-event payloads as materialised at encode time: a = d[atom] * value (:305), ||a|| (:410)
@@ -458,7 +460,7 @@ def sparse_feature_map(signal, d, n_steps=100, device=None, approx=None, pooling
         atom, lag, gain, residual, _ = _sparse_code_dense(signal.to(dev), d_unit, n_steps, approx, None, None,
                                                           False, None)
     else:
-        atom, lag, gain, residual = _native.encode(signal.to(dev)[:, 0, :], d_unit, n_steps)
+        atom, lag, gain, residual = _native.encode_checked(signal.to(dev)[:, 0, :], d_unit, n_steps)
     fm = torch.zeros(batch, n_atoms, n_samples, device=dev)
     if n_steps > 0:
         bidx = torch.arange(batch, device=dev)[:, None].expand_as(atom)

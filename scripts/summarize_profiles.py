@@ -15,6 +15,9 @@ os.makedirs(os.path.dirname(dst) or ".", exist_ok=True)
 
 def short(name):
     for key in ("correlate_persistent_kernel", "correlate_mfma_kernel", "correlate_naive_kernel",
+                "fft_screen_wave_kernel", "fft_screen_kernel", "fft_correlate_kernel", "fft_refine_valu_kernel",
+                "fft_refine_kernel", "fft_select_a_kernel", "fft_select_fused_kernel", "fft_window_kernel",
+                "fft_dict_kernel", "fft_twiddle_kernel", "fft_mark_overflow_kernel",
                 "select_subtract_kernel", "unit_norm_kernel", "init_residual_kernel", "copy_residual_kernel",
                 "dict_image_kernel"):
         if key in name:
@@ -56,10 +59,10 @@ if fs:
     n = collections.defaultdict(int)
     seen = set()
     for r in csv.DictReader(open(fs[0])):
-        if "correlate" not in r["Kernel_Name"]:
+        if "correlate" not in r["Kernel_Name"] and "fft_screen" not in r["Kernel_Name"]:
             continue
         d = int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
-        kind = "full_pass" if d > 3e6 else "incremental"
+        kind = "full_pass" if d > (5e5 if "fft_screen" in r["Kernel_Name"] else 3e6) else "incremental"
         agg[kind][r["Counter_Name"]] += float(r["Counter_Value"])
         if r["Dispatch_Id"] not in seen:
             seen.add(r["Dispatch_Id"])
@@ -71,20 +74,22 @@ if fs:
         sq[kind] = {
             "launches": n[kind], "avg_us": round(dur[kind] / n[kind] / 1e3, 2),
             "clock_GHz": round(cyc / dur[kind], 3),
-            "mfma_pipe_busy_frac": round(v["SQ_VALU_MFMA_BUSY_CYCLES"] / (cyc * 1024), 4),  # 256 CUs x 4 SIMDs
-            "mfma_instructions": v["SQ_INSTS_VALU_MFMA_F32"],
+            "mfma_pipe_busy_frac": round(v.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0) / (cyc * 1024), 4),  # 256 CUs x 4 SIMDs
+            "mfma_instructions": v.get("SQ_INSTS_VALU_MFMA_F32", 0.0),
+            "valu_active_frac_of_wave_cycles": round(v.get("SQ_ACTIVE_INST_VALU", 0.0) / v["SQ_WAVE_CYCLES"], 4),
+            "lds_bank_conflict_frac_of_lds_cycles": round(v.get("SQ_LDS_BANK_CONFLICT", 0.0) / max(v.get("SQ_LDS_IDX_ACTIVE", 0.0), 1.0), 4),
             "waves_per_simd": round(v["SQ_WAVE_CYCLES"] * 4 / (cyc * 1024), 3),
             "wait_any_frac_of_wave_cycles": round(v["SQ_WAIT_ANY"] / v["SQ_WAVE_CYCLES"], 4),
             "wait_inst_any_frac_of_wave_cycles": round(v["SQ_WAIT_INST_ANY"] / v["SQ_WAVE_CYCLES"], 4),
         }
-    summary["sq_counters_correlate_kernel"] = sq
+    summary["sq_counters_dominant_kernel"] = sq
 
 # HBM traffic per launch of the dominant kernel, corrected as MI355X_MICROARCH.md prescribes:
 # FETCH_SIZE (KB) is doubled on gfx950 for wide coalesced reads; WRITE_SIZE is exact.
 fk = summary.get("FETCH_SIZE_KB", {})
 wk = summary.get("WRITE_SIZE_KB", {})
 for k in fk:
-    if "correlate" in k and k in wk:
+    if ("correlate" in k or "fft_screen" in k) and k in wk:
         summary["hbm_traffic_bytes_per_launch_" + k.split("<")[0]] = int(
             (2 * fk[k]["avg_per_launch"] + wk[k]["avg_per_launch"]) * 1024)
 json.dump(summary, open(dst + "_summary.json", "w"), indent=1)
