@@ -179,3 +179,24 @@ def test_encode_packed_fast_interface_and_large_batch():
     for r in range(1, 400):
         assert torch.equal(p["atom"][3 * r:3 * r + 3], p["atom"][:3])
         assert torch.equal(p["gain"][3 * r:3 * r + 3], p["gain"][:3])
+
+
+def test_default_schedule_falls_back_when_the_fft_screen_overflows(oracle):
+    """A constant signal makes hundreds of near-equal cells: the FFT screen marks the segment (gain = NaN)
+    and the default schedule re-encodes it on the incremental path -- the caller sees the exact events."""
+    from mpcore import _native as nat, encode_packed
+    d = synth.make_dictionary(8, 16, seed=3)
+    du = oracle.unit_norm(d)
+    x = np.ones((2, 3000), dtype=np.float32)
+    x[1, 100:900] = synth.make_segments(1, 800, d, n_events=4, seed=9)[0]  # one ordinary segment
+    want = oracle.encode(x, du, 4)
+    raw = nat.encode(torch.from_numpy(x).to(DEV), torch.from_numpy(du).to(DEV), 4, path=nat.MP_PATH_FFT)
+    out = encode_packed(torch.from_numpy(x).to(DEV), torch.from_numpy(d).to(DEV), 4)
+    assert not torch.isnan(out["gain"]).any()
+    assert np.array_equal(out["atom"].cpu().numpy(), want["atom"])
+    assert np.array_equal(out["lag"].cpu().numpy(), want["lag"])
+    assert np.array_equal(out["gain"].cpu().numpy(), want["gain"])
+    assert np.array_equal(out["residual"].cpu().numpy(), want["residual"])
+    # whatever the raw FFT call certified is already exact
+    ok = ~torch.isnan(raw[2]).any(dim=1).cpu().numpy()
+    assert np.array_equal(raw[0].cpu().numpy()[ok], want["atom"][ok])
