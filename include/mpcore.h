@@ -56,6 +56,7 @@ extern "C" {
 #define MP_FLAG_FFT_WAVE 256 /* MP_PATH_FFT: one-wavefront-per-transform screen (M = 1024 / 2048 only)          */
 #define MP_FLAG_FFT_UNFUSED 512 /* MP_PATH_FFT: select-A / refine / select-B always as three kernels            */
 #define MP_FLAG_FFT_FUSED 1024  /* MP_PATH_FFT: ... always as one kernel (default: by cells per segment)        */
+#define MP_FLAG_OVERLAP 2048    /* two sub-batches on forked internal streams (joined before returning)           */
 #define MP_FLAG_NO_PERSISTENT 8 /* one workgroup per 4 cells instead of machine-sized persistent grid */
 
 int mp_version(void);

@@ -27,6 +27,7 @@ MP_FLAG_FFT_PREFETCH = 128
 MP_FLAG_FFT_WAVE = 256
 MP_FLAG_FFT_UNFUSED = 512
 MP_FLAG_FFT_FUSED = 1024
+MP_FLAG_OVERLAP = 2048
 
 EXPORTS = (
     "mp_version", "mp_last_error", "mp_workspace_bytes", "mp_unit_norm_f32", "mp_encode_f32",

@@ -9,9 +9,9 @@ from mpcore import synth
 shape = sys.argv[1] if len(sys.argv) > 1 else "c2"
 rounds = int(sys.argv[2]) if len(sys.argv) > 2 else 5
 A, L, N, B, K = {"c2": (512, 512, 32768, 64, 64), "c4": (4096, 2048, 131072, 16, 16)}[shape]
-variants = [("fft", 1, 0), ("fft_unfused", 1, 512), ("fft_fused", 1, 1024), ("fft_refine_mfma", 1, 32)]
+variants = [("fft", 1, 0), ("fft_overlap", 1, 2048), ("fft_fused", 1, 1024)]
 if shape == "c2":
-    variants.append(("incremental", 2, 0))
+    variants += [("incremental", 2, 0), ("incremental_overlap", 2, 2048)]
 d = synth.make_dictionary(A, L, seed=1000)
 x = torch.from_numpy(synth.make_segments(B, N, d, n_events=min(3 * K, 192), seed=1002)).cuda()
 du = nat.unit_norm(torch.from_numpy(d).cuda())

@@ -28,6 +28,8 @@ PATHS = [
     ("fft", nat.MP_PATH_FFT, 0),
     ("fft_refine_mfma", nat.MP_PATH_FFT, nat.MP_FLAG_REFINE_MFMA),
     ("fft_refine_mfma_nodma", nat.MP_PATH_FFT, nat.MP_FLAG_REFINE_MFMA | nat.MP_FLAG_NO_DMA),
+    ("fft_overlap", nat.MP_PATH_FFT, nat.MP_FLAG_OVERLAP),
+    ("incremental_overlap", nat.MP_PATH_INCREMENTAL, nat.MP_FLAG_OVERLAP),
     ("fft_unfused", nat.MP_PATH_FFT, nat.MP_FLAG_FFT_UNFUSED),
     ("fft_fused", nat.MP_PATH_FFT, nat.MP_FLAG_FFT_FUSED),
     ("fft_wave", nat.MP_PATH_FFT, nat.MP_FLAG_FFT_WAVE),
@@ -47,6 +49,7 @@ SHAPES = {
     "atom_longer_than_segment": (5, 64, 50, 2, 3, 2, 15),
     "k_chunks": (40, 1100, 3000, 2, 6, 4, 16),   # L > 512: several LDS chunks per correlation
     "many_atoms": (200, 32, 700, 1, 10, 6, 17),  # A not a multiple of the 64-atom tile
+    "split_batch": (20, 48, 900, 9, 6, 5, 18),   # B >= 8: two sub-batches on forked streams, 4 + 5 segments
 }
 
 
