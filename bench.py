@@ -95,9 +95,10 @@ def timed_encodes(x, du, steps, warmup, path, flags, group):
 
 
 def pmc_traffic(kernel="correlate"):
-    """HBM bytes per launch of the named kernel from the newest committed PMC summary
-    (profiles/rNN_summary.json: FETCH_SIZE x2 + WRITE_SIZE, separate rocprofv3 --pmc passes of this
-    same command; counters cannot be read from inside the process).  None if there is none."""
+    """HBM (fabric) bytes per launch of the named kernel from the newest committed PMC summary
+    (profiles/rNN_*_summary.json: FETCH_SIZE x2 + WRITE_SIZE, separate rocprofv3 --pmc passes of this
+    same command -- scripts/profile_round.sh; counters cannot be read from inside the process).
+    None if there is none."""
     import glob
     files = sorted(glob.glob(os.path.join(REPO, "profiles", "r*_summary.json")))
     for f in reversed(files):
@@ -107,7 +108,7 @@ def pmc_traffic(kernel="correlate"):
             continue
         for k, v in d.items():
             if k.startswith("hbm_traffic_bytes_per_launch_" + kernel):
-                return {"bytes_per_launch": v, "source": os.path.relpath(f, REPO)}
+                return v
     return None
 
 
