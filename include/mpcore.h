@@ -102,6 +102,21 @@ int mp_encode_f32(const float *signal, int64_t B, int64_t N, const float *dict_u
                   void *stream);
 
 /*
+ * The analysis loop of the reference's gradient-trained model, mp.py:54-66 (MatchingPursuit.forward):
+ * per step, spec = CONVOLUTION of the residual with the raw atoms cropped to N
+ * (modules/transfer.py:548-569 fft_convolve), top-1 over atom x time (modules/sparse.py:46-89 with
+ * n_to_keep = 1), and residual -= value^2 * atom placed at that time (mp.py:61-64: the value enters once
+ * through the one-hot atom selector and once through the time impulse).
+ *   signal [B, N], atoms [A, L] RAW (not normalised), out_atom/out_time [B, K], out_value [B, K] = the
+ *   feature-map value v of each step (the event channel is v^2 * atom), out_residual [B, N] or NULL.
+ * Same schedules (`path`), workspace and conventions as mp_encode_f32; values are exact fma chains.
+ */
+int mp_encode_conv_f32(const float *signal, int64_t B, int64_t N, const float *atoms, int64_t A,
+                       int64_t L, int K, int path, int flags, int64_t *out_atom, int64_t *out_time,
+                       float *out_value, float *out_residual, void *workspace, size_t workspace_bytes,
+                       void *stream);
+
+/*
  * Dense feature map fm[b, a, t] = sum_k r[b, t+k] * d[a, k]  (r zero beyond N), t in [0, N).
  * Replaces F.conv1d(F.pad(residual,(0,L)), d.view(A,1,L))[..., :N]
  * (modules/matchingpursuit.py:275-277, :90-92; modules/conv.py:4-9).  Serves the hooks that

@@ -189,16 +189,26 @@ __global__ void dict_image_kernel(const float *__restrict__ du, int64_t A, int64
     }
 }
 
-__global__ void init_residual_kernel(const float *__restrict__ signal, int64_t N, int64_t Ns,
+// `lead` zeros, the signal, zeros to the end of the row (lead = 0 for matching pursuit proper)
+__global__ void init_residual_kernel(const float *__restrict__ signal, int64_t N, int64_t Ns, int64_t lead,
                                      float *__restrict__ res) {
     int64_t b = blockIdx.y;
     for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < Ns;
          t += (int64_t)gridDim.x * blockDim.x)
-        res[b * Ns + t] = t < N ? signal[b * N + t] : 0.0f;
+        res[b * Ns + t] = (t >= lead && t - lead < N) ? signal[b * N + t - lead] : 0.0f;
 }
 
-__global__ void copy_residual_kernel(const float *__restrict__ res, int64_t N, int64_t Ns,
-                                     float *__restrict__ out) {
+__global__ void reverse_rows_kernel(const float *__restrict__ d, int64_t A, int64_t L, float *__restrict__ out) {
+    const int64_t total = A * L;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t a = e / L, k = e % L;
+        out[e] = d[a * L + (L - 1 - k)];
+    }
+}
+
+__global__ void copy_residual_kernel(const float *__restrict__ res_in, int64_t N, int64_t Ns,
+                                     float *__restrict__ out, int64_t lead) {
+    const float *res = res_in + lead;
     int64_t b = blockIdx.y;
     for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < N;
          t += (int64_t)gridDim.x * blockDim.x)
@@ -583,7 +593,7 @@ __global__ __launch_bounds__(256) void select_subtract_kernel(
     int *__restrict__ dirty, int64_t *__restrict__ out_atom, int64_t *__restrict__ out_lag,
     float *__restrict__ out_gain, int64_t N, int64_t L, int64_t Ns, int NBLK, int K, int k,
     const int *__restrict__ cont, const int *__restrict__ ncont, u64 *__restrict__ keys_wb,
-    float *__restrict__ ceps_wb, int64_t n_cells) {
+    float *__restrict__ ceps_wb, int64_t n_cells, int shift, int square) {
     __shared__ u64 s_key[4];
     const int b = blockIdx.x;
     const int tid = threadIdx.x;
@@ -617,26 +627,29 @@ __global__ __launch_bounds__(256) void select_subtract_kernel(
         out_lag[(int64_t)b * K + k] = lag;
         out_gain[(int64_t)b * K + k] = gain;
         if (dirty) {
-            int64_t lo = lag - L + 1; if (lo < 0) lo = 0;
-            int64_t hi = lag + L - 1; if (hi > N - 1) hi = N - 1;
+            int64_t lo = lag + shift - L + 1; if (lo < 0) lo = 0;
+            int64_t hi = lag + shift + L - 1; if (hi > N - 1) hi = N - 1;
             const int fb = (int)(lo / LAGS_PER_WAVE), lb = (int)(hi / LAGS_PER_WAVE);
             dirty[2 * b] = fb;
             dirty[2 * b + 1] = lb - fb + 1;
         }
     }
     if (keys_wb) {  // FFT path: the screen merges with atomicMax, so the cells it will redo start from 0
-        int64_t lo = lag - L + 1; if (lo < 0) lo = 0;
-        int64_t hi = lag + L - 1; if (hi > N - 1) hi = N - 1;
+        int64_t lo = lag + shift - L + 1; if (lo < 0) lo = 0;
+        int64_t hi = lag + shift + L - 1; if (hi > N - 1) hi = N - 1;
         const int fb = (int)(lo / LAGS_PER_WAVE), lb = (int)(hi / LAGS_PER_WAVE);
         const int nat = (int)(n_cells / NBLK);
         u64 *kz = keys_wb + (int64_t)b * n_cells + (int64_t)fb * nat;
         const int nz = (lb - fb + 1) * nat;
         for (int e = tid; e < nz; e += 256) kz[e] = 0ull;
     }
+    // matching pursuit: r[lag + s] -= d[atom][s] * gain (shift 0); convolution model (mp.py:61-64):
+    // the FORWARD atom lands at output sample lag, i.e. row position lag + L - 1, scaled by gain^2
     const int64_t len = (N - lag) < L ? (N - lag) : L;
-    float *r = res + (int64_t)b * Ns + lag;
+    float *r = res + (int64_t)b * Ns + lag + shift;
     const float *d = du + atom * L;
-    for (int64_t s = tid; s < len; s += 256) r[s] = __fsub_rn(r[s], __fmul_rn(d[s], gain));
+    const float g2 = square ? __fmul_rn(gain, gain) : gain;
+    for (int64_t s = tid; s < len; s += 256) r[s] = __fsub_rn(r[s], __fmul_rn(d[s], g2));
 }
 
 __global__ void fill_dirty_kernel(int *dirty, int64_t B, int first, int count) {
@@ -699,12 +712,14 @@ __global__ void gather_sum_kernel(const float *__restrict__ x, int64_t N, const 
 struct Workspace {
     float *res;
     float *img;
+    float *drev;  // time-reversed atoms (convolution model)
     u64 *keys;
     int *dirty;
     // FFT path only
     cpx *tw, *pspec, *xspec;
     float *wnorm, *ceps;
     int *cont, *ncont, *overflow;
+    float *dscale;  // max atom norm (convolution model: atoms are not unit norm)
     u64 *ekeys;
     size_t bytes;
 };
@@ -723,10 +738,12 @@ Workspace carve(const Geom &g, int path, char *base) {
     size_t cells = naive ? (size_t)g.A : (size_t)g.NAT;
     size_t o_keys = take((size_t)g.B * g.NBLK * cells * sizeof(u64));
     size_t o_dirty = take((size_t)g.B * 2 * sizeof(int));
+    size_t o_drev = take((size_t)g.A * g.L * sizeof(float));
     w.tw = w.pspec = w.xspec = nullptr;
     w.wnorm = w.ceps = nullptr;
     w.cont = w.ncont = w.overflow = nullptr;
     w.ekeys = nullptr;
+    w.dscale = nullptr;
     if (path == MP_PATH_FFT) {
         FftGeom f;
         if (make_fft_geom(g, &f)) {
@@ -739,6 +756,7 @@ Workspace carve(const Geom &g, int path, char *base) {
             size_t o_nc = take((size_t)g.B * sizeof(int));
             size_t o_ov = take((size_t)g.B * sizeof(int));
             size_t o_ek = take((size_t)g.B * (MAXCONT + 1) * sizeof(u64));
+            size_t o_ds = take(256);
             w.tw = reinterpret_cast<cpx *>(base + o_tw);
             w.pspec = reinterpret_cast<cpx *>(base + o_ps);
             w.xspec = reinterpret_cast<cpx *>(base + o_xs);
@@ -748,12 +766,14 @@ Workspace carve(const Geom &g, int path, char *base) {
             w.ncont = reinterpret_cast<int *>(base + o_nc);
             w.overflow = reinterpret_cast<int *>(base + o_ov);
             w.ekeys = reinterpret_cast<u64 *>(base + o_ek);
+            w.dscale = reinterpret_cast<float *>(base + o_ds);
         }
     }
     w.res = reinterpret_cast<float *>(base + o_res);
     w.img = reinterpret_cast<float *>(base + o_img);
     w.keys = reinterpret_cast<u64 *>(base + o_keys);
     w.dirty = reinterpret_cast<int *>(base + o_dirty);
+    w.drev = reinterpret_cast<float *>(base + o_drev);
     w.bytes = off;
     return w;
 }
@@ -865,11 +885,23 @@ int launch_naive(const Geom &g, const Workspace &w, const float *du, const int *
     return MP_OK;
 }
 
+// How a selected event changes the residual row.  Matching pursuit (modules/matchingpursuit.py:305,:328):
+// row[lag + s] -= d[atom][s] * gain.  Convolution model (mp.py:58-64): the feature map is the CONVOLUTION of
+// the residual with the raw atoms -- computed here as the correlation of the row (L - 1 leading zeros, then the
+// signal) with the time-reversed atoms -- and the update puts the FORWARD atom at output sample `lag`
+// (row position lag + L - 1) scaled by gain^2.
+struct Rule {
+    const float *du_sub;  // atoms used by the subtraction
+    int shift;            // row offset of the subtracted atom relative to the lag
+    int square;           // scale by gain^2 instead of gain
+    int64_t lead;         // leading zeros of every residual row
+};
+
 int stage_inputs(const Geom &g, const Workspace &w, int path, const float *signal, const float *du,
-                 hipStream_t st) {
+                 int64_t lead, hipStream_t st) {
     {
         dim3 grid((unsigned)((g.Ns + 255) / 256 < 1024 ? (g.Ns + 255) / 256 : 1024), (unsigned)g.B);
-        hipLaunchKernelGGL(init_residual_kernel, grid, dim3(256), 0, st, signal, g.N, g.Ns, w.res);
+        hipLaunchKernelGGL(init_residual_kernel, grid, dim3(256), 0, st, signal, g.N, g.Ns, lead, w.res);
         HIP_TRY(hipGetLastError());
     }
     if (path != MP_PATH_NAIVE) {
@@ -946,7 +978,7 @@ int fft_setup(const Geom &g, const Workspace &w, const float *du, int flags, hip
 
 // one matching-pursuit step of a (sub-)batch on stream st
 int fft_iteration(const Geom &g, const Workspace &w, const float *du, int K, int k, int flags, int64_t *out_atom,
-                  int64_t *out_lag, float *out_gain, hipStream_t st) {
+                  int64_t *out_lag, float *out_gain, const Rule &rule, hipStream_t st) {
     FftGeom f;
     if (!make_fft_geom(g, &f)) return fail(MP_ERR_UNSUPPORTED, "MP_PATH_FFT: atom too long%s");
     const size_t lds = (size_t)f.M * sizeof(cpx);
@@ -960,7 +992,7 @@ int fft_iteration(const Geom &g, const Workspace &w, const float *du, int K, int
         g_prof.begin(PROF_SELECT, st);
         MP_FFT_DISPATCH(f.logM, {
             hipLaunchKernelGGL(fft_window_kernel<LG>, dim3(nw, (unsigned)g.B), dim3(256), lds, st, w.res, g.Ns,
-                               dirty, w.tw, w.xspec, w.wnorm, f.V, f.NW);
+                               dirty, w.tw, w.xspec, w.wnorm, f.V, f.NW, rule.square ? w.dscale : (const float *)nullptr);
         })
         g_prof.end(st);
         g_prof.begin(k == 0 ? PROF_CORR_FULL : PROF_CORR_INC, st);
@@ -1011,7 +1043,7 @@ int fft_iteration(const Geom &g, const Workspace &w, const float *du, int K, int
             const size_t lds_f = (size_t)(round_up(g.L, 64) + 128) * sizeof(float);
             hipLaunchKernelGGL(fft_select_fused_kernel, dim3((unsigned)g.B), dim3(1024), lds_f, st, w.keys, w.ceps,
                                n_cells, w.res, du, w.dirty, w.overflow, out_atom, out_lag, out_gain, g.N, g.A, g.L,
-                               g.Ns, g.NBLK, g.NAT, K, k);
+                               g.Ns, g.NBLK, g.NAT, K, k, rule.du_sub, rule.shift, rule.square);
         } else {
             hipLaunchKernelGGL(fft_select_a_kernel, dim3((unsigned)g.B), dim3(1024), 0, st, w.keys, w.ceps, n_cells,
                                w.cont, w.ncont, w.ekeys, w.overflow);
@@ -1028,8 +1060,9 @@ int fft_iteration(const Geom &g, const Workspace &w, const float *du, int K, int
                                    w.cont, w.ncont, w.ekeys, g.N, g.A, g.L, g.Ns, g.NAT);
             }
             hipLaunchKernelGGL(select_subtract_kernel, dim3((unsigned)g.B), dim3(256), 0, st, w.ekeys,
-                               (int64_t)(MAXCONT + 1), w.res, du, w.dirty, out_atom, out_lag, out_gain, g.N, g.L,
-                               g.Ns, g.NBLK, K, k, w.cont, w.ncont, w.keys, w.ceps, n_cells);
+                               (int64_t)(MAXCONT + 1), w.res, rule.du_sub, w.dirty, out_atom, out_lag, out_gain, g.N,
+                               g.L, g.Ns, g.NBLK, K, k, w.cont, w.ncont, w.keys, w.ceps, n_cells, rule.shift,
+                               rule.square);
         }
         g_prof.end(st);
         HIP_TRY(hipGetLastError());
@@ -1130,10 +1163,10 @@ int mp_unit_norm_f32(const float *d, int64_t A, int64_t L, float eps, float *out
     return MP_OK;
 }
 
-int mp_encode_f32(const float *signal, int64_t B, int64_t N, const float *dict_unit, int64_t A,
-                  int64_t L, int K, int path, int flags, int64_t *out_atom, int64_t *out_lag,
-                  float *out_gain, float *out_residual, void *workspace, size_t workspace_bytes,
-                  void *stream) {
+static int encode_impl(const float *signal, int64_t B, int64_t N, const float *dict_in, int64_t A,
+                       int64_t L, int K, int path, int flags, int64_t *out_atom, int64_t *out_lag,
+                       float *out_gain, float *out_residual, void *workspace, size_t workspace_bytes,
+                       void *stream, bool conv_model) {
     int rc = check_shape(B, N, A, L, K);
     if (rc) return rc;
     if (path != MP_PATH_DIRECT && path != MP_PATH_INCREMENTAL && path != MP_PATH_NAIVE && path != MP_PATH_FFT)
@@ -1141,7 +1174,7 @@ int mp_encode_f32(const float *signal, int64_t B, int64_t N, const float *dict_u
     if (path == MP_PATH_NAIVE && (B > 65535 || A > 65535))
         return fail(MP_ERR_ARG, "MP_PATH_NAIVE: B and A must be <= 65535%s");
     if (B == 0) return MP_OK;
-    if (!signal || !dict_unit || !workspace) return fail(MP_ERR_ARG, "null pointer%s");
+    if (!signal || !dict_in || !workspace) return fail(MP_ERR_ARG, "null pointer%s");
     if (K > 0 && (!out_atom || !out_lag || !out_gain)) return fail(MP_ERR_ARG, "null output%s");
     if (reinterpret_cast<uintptr_t>(workspace) % 256) return fail(MP_ERR_WORKSPACE, "workspace not 256-byte aligned%s");
     Geom g = make_geom_for(B, N, A, L, path, flags);
@@ -1149,9 +1182,22 @@ int mp_encode_f32(const float *signal, int64_t B, int64_t N, const float *dict_u
     if (w.bytes > workspace_bytes) return fail(MP_ERR_WORKSPACE, "workspace too small%s");
     hipStream_t st = static_cast<hipStream_t>(stream);
 
-    rc = stage_inputs(g, w, path, signal, dict_unit, st);
+    // dictionary the correlation runs against, and the residual update rule
+    const float *dict_unit = dict_in;
+    Rule rule{dict_in, 0, 0, 0};
+    if (conv_model) {
+        hipLaunchKernelGGL(reverse_rows_kernel, dim3(256), dim3(256), 0, st, dict_in, A, L, w.drev);
+        HIP_TRY(hipGetLastError());
+        dict_unit = w.drev;
+        rule = Rule{dict_in, (int)(L - 1), 1, L - 1};
+    }
+    rc = stage_inputs(g, w, path, signal, dict_unit, rule.lead, st);
     if (rc) return rc;
     if (path == MP_PATH_FFT && (rc = fft_setup(g, w, dict_unit, flags, st))) return rc;
+    if (path == MP_PATH_FFT && conv_model) {
+        hipLaunchKernelGGL(max_row_norm_kernel, dim3(1), dim3(256), 0, st, dict_in, A, L, w.dscale);
+        HIP_TRY(hipGetLastError());
+    }
 
     // MP_FLAG_OVERLAP: segments are independent, so the batch can be cut into two sub-batches on forked
     // streams -- while one is in its short, latency-bound select kernels the other keeps the CUs busy.
@@ -1180,7 +1226,7 @@ int mp_encode_f32(const float *signal, int64_t B, int64_t N, const float *dict_u
             int64_t *oa = out_atom + b0 * K, *ol = out_lag + b0 * K;
             float *og = out_gain + b0 * K;
             if (path == MP_PATH_FFT) {
-                if ((rc = fft_iteration(gq, wq, dict_unit, K, k, flags, oa, ol, og, sq))) return rc;
+                if ((rc = fft_iteration(gq, wq, dict_unit, K, k, flags, oa, ol, og, rule, sq))) return rc;
                 continue;
             }
             const bool full = (k == 0) || !incremental;
@@ -1194,9 +1240,9 @@ int mp_encode_f32(const float *signal, int64_t B, int64_t N, const float *dict_u
             if (rc) return rc;
             g_prof.begin(PROF_SELECT, sq);
             hipLaunchKernelGGL(select_subtract_kernel, dim3((unsigned)gq.B), dim3(256), 0, sq, wq.keys, cells, wq.res,
-                               dict_unit, incremental ? wq.dirty : nullptr, oa, ol, og, N, L, g.Ns, g.NBLK, K, k,
+                               rule.du_sub, incremental ? wq.dirty : nullptr, oa, ol, og, N, L, g.Ns, g.NBLK, K, k,
                                (const int *)nullptr, (const int *)nullptr, (u64 *)nullptr, (float *)nullptr,
-                               (int64_t)0);
+                               (int64_t)0, rule.shift, rule.square);
             g_prof.end(sq);
             HIP_TRY(hipGetLastError());
         }
@@ -1213,10 +1259,26 @@ int mp_encode_f32(const float *signal, int64_t B, int64_t N, const float *dict_u
     }
     if (out_residual) {
         dim3 grid((unsigned)((N + 255) / 256 < 1024 ? (N + 255) / 256 : 1024), (unsigned)B);
-        hipLaunchKernelGGL(copy_residual_kernel, grid, dim3(256), 0, st, w.res, N, g.Ns, out_residual);
+        hipLaunchKernelGGL(copy_residual_kernel, grid, dim3(256), 0, st, w.res, N, g.Ns, out_residual, rule.lead);
         HIP_TRY(hipGetLastError());
     }
     return MP_OK;
+}
+
+int mp_encode_f32(const float *signal, int64_t B, int64_t N, const float *dict_unit, int64_t A,
+                  int64_t L, int K, int path, int flags, int64_t *out_atom, int64_t *out_lag,
+                  float *out_gain, float *out_residual, void *workspace, size_t workspace_bytes,
+                  void *stream) {
+    return encode_impl(signal, B, N, dict_unit, A, L, K, path, flags, out_atom, out_lag, out_gain, out_residual,
+                       workspace, workspace_bytes, stream, false);
+}
+
+int mp_encode_conv_f32(const float *signal, int64_t B, int64_t N, const float *atoms, int64_t A,
+                       int64_t L, int K, int path, int flags, int64_t *out_atom, int64_t *out_time,
+                       float *out_value, float *out_residual, void *workspace, size_t workspace_bytes,
+                       void *stream) {
+    return encode_impl(signal, B, N, atoms, A, L, K, path, flags, out_atom, out_time, out_value, out_residual,
+                       workspace, workspace_bytes, stream, true);
 }
 
 int mp_feature_map_f32(const float *residual, int64_t B, int64_t N, const float *dict_unit,
@@ -1231,7 +1293,7 @@ int mp_feature_map_f32(const float *residual, int64_t B, int64_t N, const float 
     Workspace w = carve(g, MP_PATH_DIRECT, static_cast<char *>(workspace));
     if (w.bytes > workspace_bytes) return fail(MP_ERR_WORKSPACE, "workspace too small%s");
     hipStream_t st = static_cast<hipStream_t>(stream);
-    rc = stage_inputs(g, w, MP_PATH_DIRECT, residual, dict_unit, st);
+    rc = stage_inputs(g, w, MP_PATH_DIRECT, residual, dict_unit, 0, st);
     if (rc) return rc;
     return launch_correlate<true>(g, w, nullptr, fm, 0, st);
 }

@@ -32,7 +32,7 @@ MP_FLAG_OVERLAP = 2048
 EXPORTS = (
     "mp_version", "mp_last_error", "mp_workspace_bytes", "mp_unit_norm_f32", "mp_encode_f32",
     "mp_feature_map_f32", "mp_scatter_f32", "mp_scatter_rows_f32", "mp_gather_sum_f32",
-    "mp_profile_enable", "mp_profile_read", "mp_fft_c2c_f32",
+    "mp_profile_enable", "mp_profile_read", "mp_fft_c2c_f32", "mp_encode_conv_f32",
 )
 
 _lib = None
@@ -59,6 +59,7 @@ def lib():
         L.mp_unit_norm_f32.argtypes = [vp, i64, i64, fp, vp, vp]
         L.mp_encode_f32.argtypes = [vp, i64, i64, vp, i64, i64, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                     vp, vp, vp, vp, vp, ctypes.c_size_t, vp]
+        L.mp_encode_conv_f32.argtypes = L.mp_encode_f32.argtypes
         L.mp_feature_map_f32.argtypes = [vp, i64, i64, vp, i64, i64, vp, vp, ctypes.c_size_t, vp]
         L.mp_scatter_f32.argtypes = [vp, vp, vp, vp, i64, vp, i64, i64, vp, i64, i64, vp]
         L.mp_scatter_rows_f32.argtypes = [vp, vp, vp, i64, i64, vp, i64, i64, vp]
@@ -150,9 +151,10 @@ def encode_checked(signal, dict_unit, n_steps, flags=0, want_residual=True):
     return atom, lag, gain, residual
 
 
-def encode(signal, dict_unit, n_steps, path=MP_PATH_INCREMENTAL, flags=0, want_residual=True):
+def encode(signal, dict_unit, n_steps, path=MP_PATH_INCREMENTAL, flags=0, want_residual=True, conv_model=False):
     """signal [B,N] f32 cuda, dict_unit [A,L] f32 cuda -> (atom[B,K] i64, lag[B,K] i64,
-    gain[B,K] f32, residual[B,N] f32 | None), all on signal.device, asynchronous."""
+    gain[B,K] f32, residual[B,N] f32 | None), all on signal.device, asynchronous.
+    conv_model=True: mp_encode_conv_f32 (the analysis loop of mp.py's model; `dict_unit` = raw atoms)."""
     signal = _f32(signal)
     dict_unit = _f32(dict_unit)
     _require_cuda(signal, dict_unit)
@@ -170,10 +172,11 @@ def encode(signal, dict_unit, n_steps, path=MP_PATH_INCREMENTAL, flags=0, want_r
     ws = torch.empty(nbytes + 256, dtype=torch.uint8, device=dev)
     off = (-ws.data_ptr()) % 256
     with torch.cuda.device(dev):
-        rc = lib().mp_encode_f32(_ptr(signal), B, N, _ptr(dict_unit), A, L, K, int(path), int(flags),
+        fn = lib().mp_encode_conv_f32 if conv_model else lib().mp_encode_f32
+        rc = fn(_ptr(signal), B, N, _ptr(dict_unit), A, L, K, int(path), int(flags),
                                  _ptr(atom), _ptr(lag), _ptr(gain), _ptr(residual),
                                  ctypes.c_void_p(ws.data_ptr() + off), nbytes, _stream(signal))
-    _check(rc, "mp_encode_f32")
+    _check(rc, "mp_encode_conv_f32" if conv_model else "mp_encode_f32")
     # the workspace must outlive the asynchronous kernels: tie it to the stream
     ws.record_stream(torch.cuda.current_stream(dev))
     return atom, lag, gain, residual

@@ -1,0 +1,138 @@
+"""The reference's gradient-trained dictionary model (/root/reference/mp.py:32-107) on the native encoder.
+
+`MatchingPursuit` keeps mp.py's constructor, parameter (`atoms` [1, A, L], raw, U(-0.01, 0.01)) and
+`forward(audio[B,1,N]) -> channels[B,K,N]`.  What the reference does per step (mp.py:58-65):
+
+    spec     = fft_convolve(residual, atoms_padded)        # CONVOLUTION, modules/transfer.py:548-569
+    v, a, t  = top-1 of spec over atom x time              # sparsify2(spec, 1), modules/sparse.py:46-89
+    b        = v * atoms[a]  (*)  v * delta(t)             # = v^2 * atoms[a] placed at t, cropped to N
+    residual = residual - b ;  channels[:, i] = b
+
+Here the K analysis steps (the whole cost: a feature map over A x N per step) run in one call of
+`mp_encode_conv_f32`; the channels and the gradient are then rebuilt from the K events with window-sized
+tensor operations (B x L per step).  The picks (a, t) are constants of the graph, exactly as argmax /
+top-k indices are in the reference; the value v and the placed atom carry the gradient:
+
+    v_i = sum_k r_i[t_i - k] * atoms[a_i][k],    b_i[n] = v_i^2 * atoms[a_i][n - t_i],    r_{i+1} = r_i - b_i.
+
+`train_step` adds what config 5 of BASELINE.json asks for: the loss of the reference's training loop
+(`iterative_loss`, mp.py:104) and one all-reduce of the [A, L] dictionary gradient across ranks.
+"""
+import torch
+from torch import nn
+
+from . import _native, dist as _dist
+from .iterative import iterative_loss
+from .matchingpursuit import _compute_device
+
+
+class _ConvModelFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, audio, atoms, n_iterations, path):
+        # audio [B, N], atoms [A, L]
+        B, N = audio.shape
+        A, L = atoms.shape
+        with torch.no_grad():
+            a_idx, t_idx, v, residual = _native.encode(audio, atoms, n_iterations, path=path, conv_model=True)
+            if path == _native.MP_PATH_FFT and bool(torch.isnan(v).any()):  # a screen overflowed: exact fallback
+                a_idx, t_idx, v, residual = _native.encode(audio, atoms, n_iterations,
+                                                           path=_native.MP_PATH_INCREMENTAL, conv_model=True)
+            K = n_iterations
+            j = torch.arange(L, device=audio.device)
+            pos = t_idx[:, :, None] + j[None, None, :]                      # [B, K, L] output sample of atom tap j
+            ok = pos < N
+            vals = (v * v)[:, :, None] * atoms[a_idx]                       # v^2 * atom
+            channels = torch.zeros(B, K, N, device=audio.device, dtype=audio.dtype)
+            channels.scatter_add_(2, pos.clamp(max=N - 1), torch.where(ok, vals, torch.zeros_like(vals)))
+        ctx.save_for_backward(atoms, a_idx, t_idx, v, residual)
+        ctx.shape = (B, N, A, L, K)
+        return channels
+
+    @staticmethod
+    def backward(ctx, grad_channels):
+        atoms, a_idx, t_idx, v, r = ctx.saved_tensors
+        B, N, A, L, K = ctx.shape
+        dev = atoms.device
+        j = torch.arange(L, device=dev)
+        bidx = torch.arange(B, device=dev)[:, None]
+        g_atoms = torch.zeros_like(atoms)
+        lam = torch.zeros(B, N, device=dev, dtype=atoms.dtype)   # d loss / d r_{i+1}
+        r = r.clone()                                             # r_K, walked back to r_0
+        for i in range(K - 1, -1, -1):
+            a = a_idx[:, i]
+            t = t_idx[:, i]
+            vi = v[:, i]
+            d = atoms[a]                                          # [B, L]
+            pos = t[:, None] + j[None, :]                         # where b_i lives
+            ok = pos < N
+            posc = pos.clamp(max=N - 1)
+            # r_i = r_{i+1} + b_i
+            b_i = torch.where(ok, (vi * vi)[:, None] * d, torch.zeros_like(d))
+            r.scatter_add_(1, posc, b_i)
+            gb = grad_channels[:, i, :] - lam                     # d loss / d b_i
+            gw = torch.where(ok, gb.gather(1, posc), torch.zeros_like(d))
+            dv = 2.0 * vi * (gw * d).sum(-1)                      # through b_i = v^2 * atom
+            # window of r_i the value looked at: r_i[t - k], zero for negative indices
+            back = t[:, None] - j[None, :]
+            okb = back >= 0
+            backc = back.clamp(min=0)
+            rw = torch.where(okb, r.gather(1, backc), torch.zeros_like(d))
+            g_atoms.index_add_(0, a, (vi * vi)[:, None] * gw + dv[:, None] * rw)
+            # d loss / d r_i = lam (through r_{i+1} = r_i - b_i) + dv * d v_i / d r_i
+            lam = lam.scatter_add(1, backc, torch.where(okb, dv[:, None] * d, torch.zeros_like(d)))
+        return lam, g_atoms, None, None
+
+
+class MatchingPursuit(nn.Module):
+    """mp.py:32-67.  `path`: the native schedule (default: the fastest exact one)."""
+
+    def __init__(self, n_atoms: int, atom_samples: int, n_samples: int, n_iterations: int, path=None):
+        super().__init__()
+        self.n_atoms = n_atoms
+        self.atom_samples = atom_samples
+        self.n_samples = n_samples
+        self.n_iterations = n_iterations
+        self.path = path
+        self.atoms = nn.Parameter(torch.zeros(1, n_atoms, atom_samples).uniform_(-0.01, 0.01))
+
+    @property
+    def normalized_atoms(self):
+        """mp.py:43-49: the atoms zero-padded to the signal length (despite the name, not normalised)."""
+        pad = torch.zeros(1, self.n_atoms, self.n_samples - self.atom_samples, device=self.atoms.device)
+        return torch.cat([self.atoms, pad], dim=-1)
+
+    def forward(self, audio: torch.Tensor) -> torch.Tensor:
+        batch, _, time = audio.shape
+        dev = _compute_device(self.atoms)
+        path = self.path if self.path is not None else _native.default_path(self.atom_samples)
+        x = audio.reshape(batch, time).to(dev, torch.float32).contiguous()
+        channels = _ConvModelFn.apply(x, self.atoms[0].to(dev), self.n_iterations, path)
+        return channels.to(audio.device)
+
+
+def all_reduce_gradients(params, group=None, average=True):
+    """One flat all-reduce of the gradients (RCCL over xGMI with the nccl backend); identity without a
+    process group.  For the 512 x 512 dictionary that is a single 1 MiB message per step."""
+    grads = [p.grad for p in params if p.grad is not None]
+    if not grads or not _dist.is_distributed(group):
+        return
+    flat = torch.cat([g.reshape(-1) for g in grads])
+    flat = _dist.all_reduce_sum(flat, group)
+    if average:
+        flat = flat / _dist.rank_world(group)[1]
+    off = 0
+    for g in grads:
+        g.copy_(flat[off:off + g.numel()].view_as(g))
+        off += g.numel()
+
+
+def train_step(model, optimizer, target, transform, group=None):
+    """One step of mp.py:96-107: forward, iterative_loss, backward, (all-reduce,) optimiser step.
+    `target` is this rank's shard of the global batch.  Returns the local loss (a python float)."""
+    optimizer.zero_grad()
+    recon = model(target)
+    loss = iterative_loss(target, recon, transform)
+    loss.backward()
+    all_reduce_gradients(list(model.parameters()), group)
+    optimizer.step()
+    return float(loss.item())

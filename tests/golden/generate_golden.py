@@ -206,6 +206,53 @@ def main():
                         soft_dirac_grad=xt.grad.numpy(), x3=x3, sparse=sp.numpy(), packed=packed.numpy(),
                         one_hot=onehot.numpy())
 
+    # the gradient-trained model of mp.py:32-67 (class MatchingPursuit) + iterative_loss: forward channels,
+    # per-step picks, loss and d loss / d atoms.  mp.py itself imports conjure / matplotlib-Qt / data; the class
+    # and modules/transfer.py:548-569 fft_convolve are taken from their ASTs and executed on their own.
+    import functools
+    from torch import nn as _nn
+    from torch.nn import functional as _F
+    sparse_mod = importlib.import_module("modules.sparse")
+    picks = []
+
+    def sparsify2_recording(x, n_to_keep=8):
+        out = sparse_mod.sparsify2(x, n_to_keep=n_to_keep)
+        flat = x.reshape(x.shape[0], -1)
+        v, idx = torch.topk(flat, k=2, dim=-1)
+        picks.append((idx[:, 0] // x.shape[-1], idx[:, 0] % x.shape[-1], v.detach().clone()))
+        return out
+
+    tr_src = ast.parse(open(os.path.join(REF, "modules", "transfer.py")).read())
+    fc = [n for n in tr_src.body if isinstance(n, ast.FunctionDef) and n.name == "fft_convolve"]
+    mp_src = ast.parse(open(os.path.join(REF, "mp.py")).read())
+    cls = [n for n in mp_src.body if isinstance(n, ast.ClassDef) and n.name == "MatchingPursuit"]
+    ns = {"torch": torch, "nn": _nn, "F": _F, "reduce": functools.reduce, "sparsify2": sparsify2_recording}
+    exec(compile(ast.Module(body=fc + cls, type_ignores=[]), "mp.py<extract>", "exec"), ns)
+    A_, L_, N_, K_, B_ = 12, 32, 512, 5, 2
+    rng = np.random.Generator(np.random.PCG64(1111))
+    atoms0 = (rng.uniform(-1, 1, (1, A_, L_)) * 0.22).astype(np.float32)
+    dsyn = synth.make_dictionary(A_, L_, seed=1111)
+    target = synth.make_segments(B_, N_, dsyn, n_events=5, seed=1112)
+    model = ns["MatchingPursuit"](n_atoms=A_, atom_samples=L_, n_samples=N_, n_iterations=K_)
+    with torch.no_grad():
+        model.atoms.copy_(torch.from_numpy(atoms0))
+    tt = torch.from_numpy(target)[:, None, :]
+    channels = model.forward(tt)
+
+    def tf_small(t):
+        return stft_mod.stft(t, 64, 16, pad=True)
+
+    loss = itns["iterative_loss"](tt, channels, tf_small)
+    loss.backward()
+    gaps = [float(((v[:, 0] - v[:, 1]) / v[:, 0].abs()).min()) for _, _, v in picks]
+    np.savez_compressed(os.path.join(HERE, "mp_model.npz"), atoms=atoms0, target=target,
+                        channels=channels.detach().numpy(), loss=np.float64(loss.item()),
+                        atoms_grad=model.atoms.grad.numpy(),
+                        pick_atom=np.stack([p[0].numpy() for p in picks], 1),
+                        pick_time=np.stack([p[1].numpy() for p in picks], 1),
+                        pick_top2=np.stack([p[2].numpy() for p in picks], 1), n_iterations=np.int64(K_))
+    report.append(("mp_model", min(gaps), None, None))
+
     print("fixture report (name, min relative top-2 gap, residual dB, direct==fft picks):")
     for r in report:
         print("  ", r)

@@ -44,6 +44,14 @@ def _worker(rank, world, port, atom_full, ret):
     x = torch.arange(8, dtype=torch.float64) * (rank + 1)
     s = mpdist.all_reduce_sum(x.clone())
     assert torch.equal(s, torch.arange(8, dtype=torch.float64) * 3)
+    # config 5: the [A, L] dictionary gradient is averaged over ranks with one flat all-reduce
+    from mpcore.model import all_reduce_gradients
+    p1 = torch.nn.Parameter(torch.zeros(4, 6))
+    p2 = torch.nn.Parameter(torch.zeros(3))
+    p1.grad = torch.full((4, 6), float(rank + 1))
+    p2.grad = torch.arange(3, dtype=torch.float32) * (rank + 1)
+    all_reduce_gradients([p1, p2])
+    assert torch.equal(p1.grad, torch.full((4, 6), 1.5)) and torch.equal(p2.grad, torch.arange(3.0) * 1.5)
     # bench.py's timing reduction: max over ranks
     t = mpdist.all_reduce_max(torch.tensor([0.5 + rank], dtype=torch.float64))
     assert t.item() == 1.5

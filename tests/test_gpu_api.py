@@ -200,3 +200,55 @@ def test_default_schedule_falls_back_when_the_fft_screen_overflows(oracle):
     # whatever the raw FFT call certified is already exact
     ok = ~torch.isnan(raw[2]).any(dim=1).cpu().numpy()
     assert np.array_equal(raw[0].cpu().numpy()[ok], want["atom"][ok])
+
+
+def _stft_small(t):
+    frames = t.shape[-1] // 16
+    t = torch.nn.functional.pad(t, (0, 64)).unfold(-1, 64, 16)
+    t = t * torch.hann_window(64, device=t.device)[None, None, :]
+    return torch.abs(torch.fft.rfft(t, norm="ortho"))[:, :, :frames, :]
+
+
+@pytest.mark.parametrize("path", ["fft", "incremental", "direct"])
+def test_gradient_trained_model_matches_reference(golden_dir, path):
+    """mp.py's MatchingPursuit (BASELINE configs[4]): picks, channels, loss and d loss / d atoms against the
+    reference's own class (run from its AST by tests/golden/generate_golden.py)."""
+    from mpcore import _native as nat
+    from mpcore.model import MatchingPursuit
+    from mpcore.iterative import iterative_loss
+    z = np.load(os.path.join(golden_dir, "mp_model.npz"))
+    _, A, L = z["atoms"].shape
+    B, N = z["target"].shape
+    K = int(z["n_iterations"])
+    p = {"fft": nat.MP_PATH_FFT, "incremental": nat.MP_PATH_INCREMENTAL, "direct": nat.MP_PATH_DIRECT}[path]
+    model = MatchingPursuit(A, L, N, K, path=p).to(DEV)
+    with torch.no_grad():
+        model.atoms.copy_(torch.from_numpy(z["atoms"]))
+    target = torch.from_numpy(z["target"]).to(DEV)[:, None, :]
+    # the analysis loop alone: same picks, same values
+    a_idx, t_idx, v, _ = nat.encode(target[:, 0], model.atoms[0].detach(), K, path=p, conv_model=True)
+    assert np.array_equal(a_idx.cpu().numpy(), z["pick_atom"]) and np.array_equal(t_idx.cpu().numpy(), z["pick_time"])
+    assert np.abs(v.cpu().numpy() - z["pick_top2"][..., 0]).max() <= 2e-5 * np.abs(z["pick_top2"]).max()
+    channels = model(target)
+    assert channels.shape == (B, K, N)
+    scale = np.abs(z["channels"]).max()
+    assert np.abs(channels.detach().cpu().numpy() - z["channels"]).max() <= 5e-5 * scale
+    loss = iterative_loss(target, channels, _stft_small)
+    assert abs(loss.item() - float(z["loss"])) <= 1e-4 * abs(float(z["loss"]))
+    loss.backward()
+    g = model.atoms.grad.cpu().numpy()
+    assert np.abs(g - z["atoms_grad"]).max() <= 2e-3 * np.abs(z["atoms_grad"]).max()
+
+
+def test_model_train_step_reduces_loss():
+    from mpcore.model import MatchingPursuit, train_step
+    torch.manual_seed(0)
+    d = synth.make_dictionary(32, 64, seed=31)
+    x = torch.from_numpy(synth.make_segments(4, 2048, d, n_events=8, seed=31)).to(DEV)[:, None, :]
+    model = MatchingPursuit(32, 64, 2048, 8).to(DEV)
+    with torch.no_grad():
+        model.atoms.mul_(8.0)
+    opt = torch.optim.Adam(model.parameters(), lr=2e-3)
+    losses = [train_step(model, opt, x, _stft_small) for _ in range(12)]
+    assert all(np.isfinite(losses))
+    assert min(losses[-3:]) < losses[0]
