@@ -253,6 +253,46 @@ def main():
                         pick_top2=np.stack([p[2].numpy() for p in picks], 1), n_iterations=np.int64(K_))
     report.append(("mp_model", min(gaps), None, None))
 
+    # multiband wrapper (modules/multibanddict.py:53-473, modules/decompose.py).  multibanddict.py imports
+    # zounds only for a default-argument value (SR22050(), :63): a namespace with that one name stands in.
+    zs = types.ModuleType("zounds")
+    zs.SampleRate = object
+    zs.SR22050 = lambda: None
+    sys.modules["zounds"] = zs
+    dec = importlib.import_module("modules.decompose")
+    mb = importlib.import_module("modules.multibanddict")
+    rng = np.random.Generator(np.random.PCG64(1212))
+    n_mb = 2048
+    dsyn = synth.make_dictionary(16, 64, seed=1212)
+    xm = synth.make_segments(2, n_mb, dsyn, n_events=6, seed=1213)
+    xt = torch.from_numpy(xm)[:, None, :]
+    split = dec.fft_frequency_decompose(xt, 512)
+    sizes = sorted(split.keys())
+    specs = []
+    band_dicts = {}
+    for si, size in enumerate(sizes):
+        spec = mb.BandSpec(size, n_atoms=8, atom_size=32, signal_samples=n_mb, is_lowest_band=(si == 0))
+        draw = rng.uniform(-1, 1, (8, 32)).astype(np.float32)
+        spec.d = norm.unit_norm(torch.from_numpy(draw))
+        band_dicts[size] = draw
+        specs.append(spec)
+    model = mb.MultibandDictionaryLearning(specs, n_mb)
+    with torch.no_grad():
+        enc = model.encode(xt, steps=4)
+        flat = model.flattened_event_tuples(enc)
+        rec = model.decode(enc)
+        rec2, _ = model.recon(xt, steps=4)
+        res_atoms = specs[1].resampled_atoms()
+    out = {f"band_{k}": v.numpy() for k, v in split.items()}
+    out.update({f"dict_{k}": v for k, v in band_dicts.items()})
+    np.savez_compressed(os.path.join(HERE, "multiband.npz"), signal=xm, sizes=np.array(sizes),
+                        recompose=dec.fft_frequency_recompose(split, n_mb).numpy(),
+                        resampled_atoms_band1=res_atoms.numpy(),
+                        flat_global=np.array([[e[0], e[1]] for e in flat], dtype=np.int64),
+                        flat_time=np.array([float(e[2]) for e in flat], dtype=np.float64),
+                        flat_amp=np.array([float(e[3]) for e in flat], dtype=np.float32),
+                        recon=rec.numpy(), recon2=rec2.numpy(), **out)
+
     print("fixture report (name, min relative top-2 gap, residual dB, direct==fft picks):")
     for r in report:
         print("  ", r)
