@@ -70,6 +70,13 @@ const char *mp_last_error(void);
  * Host pointers.  Do not enable while capturing a hipGraph.
  */
 int mp_profile_enable(int on);
+
+/* Tuning hook (process-wide; results never depend on it as long as tau stays above the transform error):
+ *   MP_TUNE_TAU         the FFT screen's error bound per unit of window norm (default 2e-5)
+ *   MP_TUNE_SCREEN_PPS  atom pairs per transform slot in the screen kernel (0 = heuristic)            */
+#define MP_TUNE_TAU 1
+#define MP_TUNE_SCREEN_PPS 2
+int mp_tune(int key, double value);
 int mp_profile_read(double *ms, int64_t *count);
 
 /* Device bytes mp_encode_f32 needs in `workspace` for this problem (0 on bad arguments). */

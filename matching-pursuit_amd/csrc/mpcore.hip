@@ -946,7 +946,9 @@ int fft_lds_attr(K kern, size_t bytes) {
 }
 
 int screen_pps_override = 0;  // tuning hook (mp_tune)
-constexpr float FFT_TAU = 1.0e-4f;  // screen error bound per unit of window norm
+// screen error bound per unit of window norm: measured max |fft - chain| is
+// 6e-7 ||window|| (scripts/screen_error.py), so 2e-5 is a >30x margin; mp_tune(MP_TUNE_TAU, x) overrides
+float FFT_TAU = 2.0e-5f;
 
 // once per encode, whole batch, on the caller's stream: twiddles, pair spectra, cleared keys / flags
 int fft_setup(const Geom &g, const Workspace &w, const float *du, int flags, hipStream_t st) {
@@ -1129,6 +1131,12 @@ size_t mp_workspace_bytes(int64_t B, int64_t N, int64_t A, int64_t L, int K, int
     size_t b64 = carve(make_geom(B, N, A, L, 64), path, nullptr).bytes;
     size_t b32 = carve(make_geom(B, N, A, L, 32), path, nullptr).bytes;
     return b64 > b32 ? b64 : b32;
+}
+
+int mp_tune(int key, double value) {
+    if (key == MP_TUNE_TAU && value > 0.0) { FFT_TAU = (float)value; return MP_OK; }
+    if (key == MP_TUNE_SCREEN_PPS) { screen_pps_override = (int)value; return MP_OK; }
+    return fail(MP_ERR_ARG, "mp_tune: unknown key or bad value%s");
 }
 
 int mp_profile_enable(int on) {

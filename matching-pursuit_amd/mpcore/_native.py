@@ -32,7 +32,7 @@ MP_FLAG_OVERLAP = 2048
 EXPORTS = (
     "mp_version", "mp_last_error", "mp_workspace_bytes", "mp_unit_norm_f32", "mp_encode_f32",
     "mp_feature_map_f32", "mp_scatter_f32", "mp_scatter_rows_f32", "mp_gather_sum_f32",
-    "mp_profile_enable", "mp_profile_read", "mp_fft_c2c_f32", "mp_encode_conv_f32",
+    "mp_profile_enable", "mp_profile_read", "mp_fft_c2c_f32", "mp_encode_conv_f32", "mp_tune",
 )
 
 _lib = None
@@ -92,6 +92,12 @@ def _f32(t):
 
 def _ptr(t):
     return ctypes.c_void_p(t.data_ptr()) if t is not None else ctypes.c_void_p(0)
+
+
+def tune(key, value):
+    """mp_tune: 1 = FFT screen tau, 2 = screen pairs-per-slot override."""
+    lib().mp_tune.argtypes = [ctypes.c_int, ctypes.c_double]
+    _check(lib().mp_tune(int(key), float(value)), "mp_tune")
 
 
 def profile_enable(on=True):

@@ -18,7 +18,8 @@ from ._native import NativeError
 
 __all__ = [
     "build_scatter_segments", "flatten_atom_dict", "sparse_code", "dictionary_learning_step",
-    "sparse_feature_map", "sparse_coding_loss", "SparseCodingLoss", "unit_norm", "torch_conv",
+    "sparse_feature_map", "sparse_coding_loss", "SparseCodingLoss", "sparse_code_to_differentiable_key_points",
+    "unit_norm", "torch_conv",
     "fft_convolve", "EventList", "encode_packed", "first_selection_order", "group_events_by_atom",
 ]
 
@@ -480,6 +481,52 @@ def sparse_coding_loss(recon, target, d, n_steps=100, device=None, approx=None, 
     r_map = r_map / mx
     t_map = t_map / mx
     return F.binary_cross_entropy(r_map, t_map)
+
+
+def sparse_code_to_differentiable_key_points(signal, d, n_steps=100, device=None):
+    """Forward values of modules/matchingpursuit.py:149-227: per event the vector
+    [value, 100 * time, residual window of `atom_size` samples centred on the event] (the reference
+    squeezes that window into `n_atoms` slots, :215, so it needs n_atoms == atom_size), events in step-major,
+    batch-minor order, plus the norm of the final residual.  `time` is the argmax of max_a fm over lags on
+    linspace(0, 1, N) -- the forward value of the reference's soft_dirac(...) @ linspace (:192); its
+    straight-through softmax gradient is not reproduced (no autograd through this function).
+    The picks come from the native encoder; the windows are cut from the residual of each step, which is
+    replayed from the events with window-sized tensor operations."""
+    signal = signal.view(signal.shape[0], 1, -1)
+    batch, _, n_samples = signal.shape
+    n_atoms, atom_size = d.shape
+    if n_atoms != atom_size:
+        raise RuntimeError(f"shape '[{n_atoms}]' is invalid for input of size {atom_size}")  # as :215 raises
+    half = atom_size // 2
+    out_dev = signal.device
+    dev = _compute_device(signal)
+    with torch.no_grad():
+        x = signal.detach().to(dev, torch.float32)[:, 0, :]
+        d_unit = _native.unit_norm(d.detach().to(dev))
+        atom, lag, gain, residual = _native.encode_checked(x, d_unit, n_steps)
+        r = x.clone()
+        j = torch.arange(atom_size, device=dev)
+        rows = torch.arange(batch, device=dev)
+        lin = torch.linspace(0, 1, n_samples, device=dev)
+        vecs = torch.zeros(n_steps, batch, 2 + atom_size, device=dev)
+        for i in range(n_steps):
+            p = lag[:, i]
+            # residual[j, 0, pos - half: pos + half] with python slice semantics (:199): a negative start
+            # wraps to the end of the array, which leaves an empty (zero-filled) window
+            start = p - half
+            idx = start[:, None] + j[None, : 2 * half]
+            valid = (start[:, None] >= 0) & (idx < n_samples)
+            win = torch.where(valid, r.gather(1, idx.clamp(0, n_samples - 1)), torch.zeros((), device=dev))
+            vecs[i, :, 0] = gain[:, i]
+            vecs[i, :, 1] = lin[p] * 100
+            vecs[i, :, 2: 2 + 2 * half] = win
+            # r -= gain * atom at lag, cropped at N
+            pos = p[:, None] + j[None, :]
+            ok = pos < n_samples
+            upd = torch.where(ok, d_unit[atom[:, i]] * gain[:, i, None], torch.zeros((), device=dev))
+            r.scatter_add_(1, pos.clamp(max=n_samples - 1), -upd)
+        return (vecs.reshape(n_steps * batch, 2 + atom_size).to(out_dev),
+                torch.norm(residual, dim=-1).view(batch, 1).to(out_dev))
 
 
 class SparseCodingLoss(nn.Module):

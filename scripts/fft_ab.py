@@ -19,8 +19,12 @@ ref = None
 times = {v[0]: [] for v in variants}
 profs = {}
 nat.profile_enable(True)
+taus = {"fft_tau1e-4": 1e-4, "fft_tau5e-6": 5e-6}
+variants += [(k, 1, 0) for k in taus]
+times.update({k: [] for k in taus})
 for r in range(rounds + 1):
     for name, path, flags in variants:
+        nat.tune(1, taus.get(name, 2e-5))
         torch.cuda.synchronize(); nat.profile_read()
         t0 = time.perf_counter()
         out = nat.encode(x, du, K, path=path, flags=flags, want_residual=False)

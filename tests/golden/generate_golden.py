@@ -253,6 +253,14 @@ def main():
                         pick_top2=np.stack([p[2].numpy() for p in picks], 1), n_iterations=np.int64(K_))
     report.append(("mp_model", min(gaps), None, None))
 
+    # sparse_code_to_differentiable_key_points (:149-227); requires n_atoms == atom_size (:215)
+    dk = synth.make_dictionary(32, 32, seed=1313)
+    xk = synth.make_segments(2, 512, dk, n_events=5, seed=1313)
+    with torch.no_grad():
+        vecs, rnorm = mp.sparse_code_to_differentiable_key_points(torch.from_numpy(xk), torch.from_numpy(dk), n_steps=4)
+    np.savez_compressed(os.path.join(HERE, "key_points.npz"), signal=xk, d_raw=dk, vecs=vecs.numpy(),
+                        residual_norm=rnorm.numpy(), n_steps=np.int64(4))
+
     # multiband wrapper (modules/multibanddict.py:53-473, modules/decompose.py).  multibanddict.py imports
     # zounds only for a default-argument value (SR22050(), :63): a namespace with that one name stands in.
     zs = types.ModuleType("zounds")

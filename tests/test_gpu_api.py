@@ -288,3 +288,14 @@ def test_multiband_encode_decode_matches_reference(golden_dir):
     model.learn(x, steps=4)
     for band in model.bands.values():
         assert abs(float(torch.norm(band.d, dim=-1).mean()) - 1.0) < 1e-4
+
+
+def test_key_points_match_reference(golden_dir):
+    z = np.load(os.path.join(golden_dir, "key_points.npz"))
+    vecs, rnorm = mp.sparse_code_to_differentiable_key_points(
+        torch.from_numpy(z["signal"]).to(DEV), torch.from_numpy(z["d_raw"]).to(DEV), n_steps=int(z["n_steps"]))
+    assert vecs.shape == z["vecs"].shape and rnorm.shape == z["residual_norm"].shape
+    assert np.abs(vecs.cpu().numpy() - z["vecs"]).max() <= 2e-5 * np.abs(z["vecs"]).max()
+    assert np.abs(rnorm.cpu().numpy() - z["residual_norm"]).max() <= 1e-5 * z["residual_norm"].max()
+    with pytest.raises(RuntimeError):  # n_atoms != atom_size cannot be viewed, as in the reference (:215)
+        mp.sparse_code_to_differentiable_key_points(torch.zeros(1, 256, device=DEV), torch.rand(8, 16, device=DEV), 2)
