@@ -1,0 +1,35 @@
+#!/usr/bin/env python3
+"""BASELINE configs[3] at full size: 4096 x 2048 dictionary, 128 x 131072-sample segments, K = 256, on the FFT
+schedule; checks the round trip and (for the first segments and steps) equality with the incremental MFMA
+schedule."""
+import os, sys, time
+import numpy as np, torch
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(REPO, "matching-pursuit_amd"))
+from mpcore import _native as nat
+from mpcore import synth
+A, L, N, B, K = 4096, 2048, 131072, 128, 256
+t0 = time.time()
+d = synth.make_dictionary(A, L, seed=4000)
+x = synth.make_segments(B, N, d, n_events=256, seed=4001)
+print(f"inputs generated in {time.time() - t0:.1f} s", flush=True)
+xd = torch.from_numpy(x).cuda()
+du = nat.unit_norm(torch.from_numpy(d).cuda())
+nat.encode(xd[:4], du, 2, path=nat.MP_PATH_FFT); torch.cuda.synchronize()
+nat.profile_enable(True); nat.profile_read()
+t0 = time.perf_counter()
+atom, lag, gain, res = nat.encode(xd, du, K, path=nat.MP_PATH_FFT)
+torch.cuda.synchronize()
+dt = time.perf_counter() - t0
+p = nat.profile_read()
+print(f"c4 full: B{B} K{K}: {dt:.3f} s -> {B * K / dt:.0f} seg-it/s; overflow segments: {int(torch.isnan(gain).any(dim=1).sum())}", flush=True)
+print({k: (round(v[0] / max(v[1], 1), 3), v[1]) for k, v in p.items()}, "ms avg, launches", flush=True)
+M = 8192
+spectra_bytes = (A // 2 + 1) * 8.0 * M
+print(f"screen: algorithmic spectra per incremental launch {B * spectra_bytes / 1e9:.2f} GB -> {B * spectra_bytes / (p['corr_inc'][0] / p['corr_inc'][1] * 1e-3) / 1e12:.2f} TB/s", flush=True)
+rec = torch.zeros_like(xd)
+nat.scatter(atom, torch.arange(B, device="cuda")[:, None].expand(B, K), lag, gain, du, rec)
+print("round trip max err", float((rec + res - xd).abs().max()), "residual dB", float(20 * torch.log10(res.norm() / xd.norm())), flush=True)
+ref = nat.encode(xd[:4], du, 16, path=nat.MP_PATH_INCREMENTAL)
+print("first 4 segments x 16 steps == incremental MFMA schedule:",
+      bool(torch.equal(ref[0], atom[:4, :16]) and torch.equal(ref[1], lag[:4, :16]) and torch.equal(ref[2], gain[:4, :16])), flush=True)
