@@ -135,9 +135,10 @@ int mp_feature_map_f32(const float *residual, int64_t B, int64_t N, const float 
                        void *stream);
 
 /*
- * Test hook: batched complex FFT of 2^log2_m points (8 <= log2_m <= 14), unscaled, forward or
- * inverse -- the radix-4 Stockham transform MP_PATH_FFT is built on.  in/out: [batch, 2^log2_m]
- * interleaved (re, im) fp32; workspace >= 8 * 2^log2_m bytes (twiddle table).
+ * Test hook: batched complex FFT of 2^log2_m points (8 <= log2_m <= 14), unscaled -- the transforms
+ * MP_PATH_FFT is built on.  inverse = 0: forward, 1: inverse (radix-4 Stockham in LDS: window and
+ * dictionary spectra), 2: inverse through the screen's mixed-radix register transform (log2_m >= 10).
+ * in/out: [batch, 2^log2_m] interleaved (re, im) fp32; workspace >= 8 * 2^log2_m bytes (twiddle table).
  */
 int mp_fft_c2c_f32(const float *in, float *out, int log2_m, int64_t batch, int inverse, void *workspace,
                    void *stream);

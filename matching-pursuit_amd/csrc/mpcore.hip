@@ -1317,6 +1317,20 @@ int mp_fft_c2c_f32(const float *in, float *out, int log2_m, int64_t batch, int i
     hipLaunchKernelGGL(fft_twiddle_kernel, dim3((M + 255) / 256), dim3(256), 0, st, tw, M);
     const size_t lds = (size_t)M * sizeof(cpx);
     int rc;
+    if (inverse == 2) {  // the screen's register transform (inverse only, M >= 1024)
+        if (log2_m < 10) return fail(MP_ERR_ARG, "mp_fft_c2c_f32: the screen transform needs log2_m >= 10%s");
+        MP_FFT_DISPATCH(log2_m, {
+            constexpr int LS = LG >= 10 ? LG : 10;
+            using C = ScreenCfg<LS>;
+            const size_t lds_s = ((size_t)C::SLOTS * C::M + C::M / 64 + 64) * sizeof(cpx);
+            if ((rc = fft_lds_attr(fft_screen_probe_kernel<LS>, lds_s))) return rc;
+            hipLaunchKernelGGL(fft_screen_probe_kernel<LS>, dim3((unsigned)((batch + C::SLOTS - 1) / C::SLOTS)),
+                               dim3(C::WG), lds_s, st, reinterpret_cast<const cpx *>(in),
+                               reinterpret_cast<cpx *>(out), tw, batch);
+        })
+        HIP_TRY(hipGetLastError());
+        return MP_OK;
+    }
     MP_FFT_DISPATCH(log2_m, {
         if ((rc = fft_lds_attr(fft_c2c_kernel<LG>, lds))) return rc;
         hipLaunchKernelGGL(fft_c2c_kernel<LG>, dim3((unsigned)batch), dim3(256), lds, st,

@@ -210,7 +210,8 @@ def feature_map(residual, dict_unit):
 
 
 def fft_c2c(x, inverse=False):
-    """Batched complex FFT test hook: x complex64 [batch, 2^k] on the device -> same shape, unscaled."""
+    """Batched complex FFT test hook: x complex64 [batch, 2^k] on the device -> same shape, unscaled.
+    inverse: False / True, or 2 for the inverse through the screen kernel's register transform."""
     _require_cuda(x)
     assert x.dtype == torch.complex64 and x.dim() == 2 and x.is_contiguous()
     batch, M = x.shape
@@ -220,7 +221,7 @@ def fft_c2c(x, inverse=False):
     ws = torch.empty(8 * M, dtype=torch.uint8, device=x.device)
     xr, outr = torch.view_as_real(x), torch.view_as_real(out)
     with torch.cuda.device(x.device):
-        rc = lib().mp_fft_c2c_f32(_ptr(xr), _ptr(outr), lg, batch, 1 if inverse else 0, _ptr(ws), _stream(x))
+        rc = lib().mp_fft_c2c_f32(_ptr(xr), _ptr(outr), lg, batch, int(inverse), _ptr(ws), _stream(x))
     _check(rc, "mp_fft_c2c_f32")
     ws.record_stream(torch.cuda.current_stream(x.device))
     return out

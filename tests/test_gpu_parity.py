@@ -196,6 +196,8 @@ def test_fft_transform_matches_numpy(log2_m):
     scale = np.abs(ref).max()
     assert np.abs(nat.fft_c2c(xd).cpu().numpy() - ref).max() <= 2e-6 * scale
     assert np.abs(nat.fft_c2c(xd, inverse=True).cpu().numpy() - refi).max() <= 2e-6 * scale
+    if log2_m >= 10:  # the screen kernel's mixed-radix register transform (packed-math asm butterflies)
+        assert np.abs(nat.fft_c2c(xd, inverse=2).cpu().numpy() - refi).max() <= 2e-6 * scale
 
 
 def test_fft_path_all_zero_and_flat_inputs(oracle):
