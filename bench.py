@@ -112,53 +112,80 @@ def pmc_traffic(kernel="correlate"):
     return None
 
 
-def roofline_fft(prof, n_segments, steps):
-    """HBM-style roofline of fft_screen_kernel: algorithmic bytes (above) / summed launch durations."""
+PROF_EVERY = 16  # hipEvent spans around the kernels of iterations 0, 16, 32, 48 of every timed encode
+
+
+def launch_times(prof, steps):
+    """Sampled HIP-event spans -> (seconds all launches of the dominant kernel took, per-kind figures).
+    An event between two kernels idles the GPU for ~10 us (scripts/prof_overhead.py: 7.5 vs 6.0 ms per
+    encode with spans around every launch), so only every PROF_EVERY-th iteration of the timed region
+    carries spans; the full pass (k = 0) is always one of them.  Totals are the sampled averages times
+    the number of launches the timed region made."""
     ms_full, n_full = prof["corr_full"]
     ms_inc, n_inc = prof["corr_inc"]
-    launches = n_full + n_inc
-    if launches == 0:
+    if n_full + n_inc == 0:
         return None
+    full_launches = steps if n_inc else steps * K_ITERS      # MP_PATH_DIRECT: every launch is a full pass
+    inc_launches = steps * (K_ITERS - 1) if n_inc else 0
+    avg_full = ms_full / max(n_full, 1)
+    avg_inc = ms_inc / max(n_inc, 1)
+    sec = (avg_full * full_launches + avg_inc * inc_launches) * 1e-3
+    launches = full_launches + inc_launches
+    return sec, {
+        "launches": launches, "avg_launch_ms": round(sec * 1e3 / launches, 5),
+        "timed_with_events": {"full_pass": n_full, "incremental": n_inc,
+                              "sampling": f"iterations k % {PROF_EVERY} == 0 of each timed encode"},
+        "full_pass_launches": full_launches, "full_pass_avg_ms": round(avg_full, 5),
+        "incremental_launches": inc_launches, "incremental_avg_ms": round(avg_inc, 5),
+    }
+
+
+def roofline_fft(prof, n_segments, steps):
+    """HBM-style roofline of fft_screen_kernel: algorithmic bytes (above) / launch durations."""
+    lt = launch_times(prof, steps)
+    if lt is None:
+        return None
+    sec, per_kind = lt
     total, full, inc = algorithmic_bytes_fft(n_segments, K_ITERS)
-    sec = (ms_full + ms_inc) * 1e-3
     achieved = total * steps / sec / 1e9
     M, V = fft_geometry()
     survey_bytes = (8.0 * ((N + L) // 2 + 1) * (A + 1) + 8.0 * N) * n_segments * K_ITERS  # SURVEY.md 8(d)
-    return {
+    out = {
         "bound": "hbm", "achieved": round(achieved, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
         "frac": round(achieved / PEAK_HBM_GBS, 4), "traffic": pmc_traffic("fft_screen"),
         "kernel": "fft_screen_kernel<11,false> (radix-16 Stockham, packed fp32)",
-        "launches": launches, "avg_launch_ms": round((ms_full + ms_inc) / launches, 5),
-        "full_pass_launches": n_full, "full_pass_avg_ms": round(ms_full / max(n_full, 1), 5),
-        "incremental_launches": n_inc, "incremental_avg_ms": round(ms_inc / max(n_inc, 1), 5),
-        "other_kernels_avg_ms_per_step": round(prof["select"][0] / max(n_full + n_inc, 1), 5),
-        "algorithmic_mb_per_launch": round(total * steps / launches / 1e6, 2),
+    }
+    out.update(per_kind)
+    out.update({
+        "other_kernels_avg_ms_per_iteration": round(prof["select"][0] / max(per_kind["timed_with_events"]["full_pass"]
+                                                    + per_kind["timed_with_events"]["incremental"], 1), 5),
+        "algorithmic_mb_per_launch": round(total * steps / per_kind["launches"] / 1e6, 2),
         "note": "algorithmic bytes = spectra the kernel's own algorithm streams (mostly L2/Infinity-Cache "
                 "hits: the 4 MiB of pair spectra are shared by all segments); the kernel is packed-fp32 "
                 "VALU / LDS limited, see DESIGN.md",
         "survey_8d_equivalent_gbs": round(survey_bytes * steps / sec / 1e9, 1),
-    }
+    })
+    return out
 
 
 def roofline_from(prof, flops_one_encode, steps):
-    ms_full, n_full = prof["corr_full"]
-    ms_inc, n_inc = prof["corr_inc"]
-    total, _, _ = flops_one_encode
-    launches = n_full + n_inc
-    if launches == 0:
+    lt = launch_times(prof, steps)
+    if lt is None:
         return None
-    sec = (ms_full + ms_inc) * 1e-3
+    sec, per_kind = lt
+    total, _, _ = flops_one_encode
     achieved = total * steps / sec / 1e12
-    return {
+    out = {
         "bound": "mfma", "achieved": round(achieved, 3), "peak": PEAK_MFMA_F32_TFLOPS, "unit": "TFLOP/s",
         "frac": round(achieved / PEAK_MFMA_F32_TFLOPS, 4), "traffic": pmc_traffic(),
         "kernel": "correlate_persistent_kernel<32,true> (v_mfma_f32_32x32x2_f32)",
-        "launches": launches, "avg_launch_ms": round((ms_full + ms_inc) / launches, 5),
-        "full_pass_launches": n_full, "full_pass_avg_ms": round(ms_full / max(n_full, 1), 5),
-        "incremental_launches": n_inc, "incremental_avg_ms": round(ms_inc / max(n_inc, 1), 5),
-        "select_avg_ms": round(prof["select"][0] / max(prof["select"][1], 1), 5),
-        "algorithmic_gflop_per_launch": round(total * steps / launches / 1e9, 3),
     }
+    out.update(per_kind)
+    out.update({
+        "select_avg_ms": round(prof["select"][0] / max(prof["select"][1], 1), 5),
+        "algorithmic_gflop_per_launch": round(total * steps / per_kind["launches"] / 1e9, 3),
+    })
+    return out
 
 
 def cpu_baseline(d, x_host, gpu_sample):
@@ -227,7 +254,7 @@ def main():
     du = nat.unit_norm(torch.from_numpy(d).to(dev))
     torch.cuda.synchronize()
 
-    nat.profile_enable(True)
+    nat.profile_enable(PROF_EVERY)
     path = PATHS[args.path]
     dt, out, prof = timed_encodes(x, du, args.steps, args.warmup, path, args.flags, group)
     atom, lag, gain, residual = [t.cpu().numpy() for t in out]

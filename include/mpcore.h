@@ -63,13 +63,15 @@ int mp_version(void);
 const char *mp_last_error(void);
 
 /*
- * Measurement hook for bench.py (not part of the reference surface): while enabled,
- * mp_encode_f32 brackets each of its kernel launches with hipEvents on the launch stream.
- * mp_profile_read synchronises, then returns total milliseconds and launch counts in
- * ms[3] / count[3] = { full correlate, incremental correlate, select+subtract }, and resets.
+ * Measurement hook for bench.py (not part of the reference surface): while enabled, mp_encode_f32
+ * brackets kernel launches with hipEvents on the launch stream.  every = 0: off; 1: every iteration;
+ * n > 1: only iterations k with k % n == 0 (an event between two kernels idles the GPU for ~10 us, so
+ * sampling keeps the timed region honest).  mp_profile_read synchronises, then returns total
+ * milliseconds and span counts in ms[3] / count[3] = { full correlate, incremental correlate,
+ * everything else (window transform, select, refine, subtract) }, and resets.
  * Host pointers.  Do not enable while capturing a hipGraph.
  */
-int mp_profile_enable(int on);
+int mp_profile_enable(int every);
 
 /* Tuning hook (process-wide; results never depend on it as long as tau stays above the transform error):
  *   MP_TUNE_TAU         the FFT screen's error bound per unit of window norm (default 2e-5)

@@ -24,6 +24,8 @@ MP_FLAG_NO_STAGGER = 16
 MP_FLAG_REFINE_MFMA = 32
 MP_FLAG_FFT_SIMPLE = 64
 MP_FLAG_FFT_PREFETCH = 128
+MP_TUNE_TAU = 1
+MP_TUNE_SCREEN_PPS = 2
 MP_FLAG_FFT_WAVE = 256
 MP_FLAG_FFT_UNFUSED = 512
 MP_FLAG_FFT_FUSED = 1024
@@ -100,8 +102,9 @@ def tune(key, value):
     _check(lib().mp_tune(int(key), float(value)), "mp_tune")
 
 
-def profile_enable(on=True):
-    _check(lib().mp_profile_enable(1 if on else 0), "mp_profile_enable")
+def profile_enable(every=1):
+    """0 / False: off; 1 / True: events around the launches of every iteration; n: every n-th iteration."""
+    _check(lib().mp_profile_enable(int(every)), "mp_profile_enable")
 
 
 def profile_read():
