@@ -967,6 +967,7 @@ int fft_setup(const Geom &g, const Workspace &w, const float *du, int flags, hip
     hipLaunchKernelGGL(fft_twiddle_kernel, dim3((f.M + 255) / 256), dim3(256), 0, st, w.tw, f.M);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemsetAsync(w.overflow, 0, (size_t)g.B * sizeof(int), st));
+    HIP_TRY(hipMemsetAsync(w.ekeys, 0, (size_t)g.B * (MAXCONT + 1) * sizeof(u64), st));
     HIP_TRY(hipMemsetAsync(w.keys, 0, (size_t)g.B * n_cells * sizeof(u64), st));
     MP_FFT_DISPATCH(f.logM, {
         if ((rc = fft_lds_attr(fft_dict_kernel<LG>, lds))) return rc;
@@ -992,14 +993,28 @@ int fft_iteration(const Geom &g, const Workspace &w, const float *du, int K, int
     const bool dma = !(flags & MP_FLAG_NO_DMA);
     const size_t lds_ref = lds_bytes(g);
     int rc;
+    // Between two screens: select-A, refine and select-B as three small kernels (the refinement of a cell
+    // spread over eight workgroups), or ONE kernel per segment when a segment has so many cells that
+    // scanning them dominates (measured: config-4 shape 190 vs 315 us per step; headline shape 35 vs 26 us).
+    // MP_FLAG_FFT_FUSED / MP_FLAG_FFT_UNFUSED force either form.  A team of workgroups per segment inside
+    // one kernel was tried and dropped: agent-scope fences between its members cost 3-13 us each.
+    const bool fused = !(flags & MP_FLAG_REFINE_MFMA) && !(flags & MP_FLAG_FFT_UNFUSED) &&
+                       ((flags & MP_FLAG_FFT_FUSED) || n_cells >= 65536);
+    // both forms leave the next step's window spectrum behind when the screen's register transform exists
+    // for this size (the stand-alone window kernel then runs before the first step only)
+    const bool b_tail = !fused && !(flags & MP_FLAG_FFT_SIMPLE) && f.logM >= 10 && f.logM <= 12;
+    const bool fused_tail = (fused && f.logM >= 10) || b_tail;
     {
         const int *dirty = k == 0 ? nullptr : w.dirty;
         const int nw = k == 0 ? f.NW : 1;
         g_prof.begin(PROF_SELECT, st);
-        MP_FFT_DISPATCH(f.logM, {
-            hipLaunchKernelGGL(fft_window_kernel<LG>, dim3(nw, (unsigned)g.B), dim3(256), lds, st, w.res, g.Ns,
-                               dirty, w.tw, w.xspec, w.wnorm, f.V, f.NW, rule.square ? w.dscale : (const float *)nullptr);
-        })
+        if (k == 0 || !fused_tail) {
+            MP_FFT_DISPATCH(f.logM, {
+                hipLaunchKernelGGL(fft_window_kernel<LG>, dim3(nw, (unsigned)g.B), dim3(256), lds, st, w.res, g.Ns,
+                                   dirty, w.tw, w.xspec, w.wnorm, f.V, f.NW,
+                                   rule.square ? w.dscale : (const float *)nullptr);
+            })
+        }
         g_prof.end(st);
         g_prof.begin(k == 0 ? PROF_CORR_FULL : PROF_CORR_INC, st);
         MP_FFT_DISPATCH(f.logM, {
@@ -1042,14 +1057,17 @@ int fft_iteration(const Geom &g, const Workspace &w, const float *du, int K, int
         g_prof.end(st);
         HIP_TRY(hipGetLastError());
         g_prof.begin(PROF_SELECT, st);
-        // one fused kernel per iteration pays off when a segment has many cells to scan (measured:
-        // config-4 shape 190 vs 315 us; headline shape 50 vs 35 us)
-        const bool fused = (flags & MP_FLAG_FFT_FUSED) || (n_cells >= 65536 && !(flags & MP_FLAG_FFT_UNFUSED));
-        if (fused && !(flags & MP_FLAG_REFINE_MFMA)) {
-            const size_t lds_f = (size_t)(round_up(g.L, 64) + 128) * sizeof(float);
-            hipLaunchKernelGGL(fft_select_fused_kernel, dim3((unsigned)g.B), dim3(1024), lds_f, st, w.keys, w.ceps,
-                               n_cells, w.res, du, w.dirty, w.overflow, out_atom, out_lag, out_gain, g.N, g.A, g.L,
-                               g.Ns, g.NBLK, g.NAT, K, k, rule.du_sub, rule.shift, rule.square);
+        if (fused) {
+            const size_t lds_chain = (size_t)(round_up(g.L, 64) + 128) * sizeof(float);
+            MP_FFT_DISPATCH(f.logM, {
+                constexpr int LT = LG >= 10 ? LG : 0;                  // 0: no tail transform
+                const size_t lds_f = lds_chain + (LT ? ((size_t)f.M + f.M / 64 + 64) * sizeof(cpx) : 0);
+                if ((rc = fft_lds_attr(fft_select_fused_kernel<LT>, lds_f))) return rc;
+                hipLaunchKernelGGL(fft_select_fused_kernel<LT>, dim3((unsigned)g.B), dim3(1024), lds_f, st, w.keys,
+                                   w.ceps, n_cells, w.res, du, w.dirty, w.overflow, out_atom, out_lag, out_gain,
+                                   g.N, g.A, g.L, g.Ns, g.NBLK, g.NAT, K, k, rule.du_sub, rule.shift, rule.square,
+                                   w.tw, w.xspec, w.wnorm, f.NW, rule.square ? w.dscale : (const float *)nullptr);
+            })
         } else {
             hipLaunchKernelGGL(fft_select_a_kernel, dim3((unsigned)g.B), dim3(1024), 0, st, w.keys, w.ceps, n_cells,
                                w.cont, w.ncont, w.ekeys, w.overflow);
@@ -1065,10 +1083,22 @@ int fft_iteration(const Geom &g, const Workspace &w, const float *du, int K, int
                 hipLaunchKernelGGL(fft_refine_valu_kernel, dim3(8, 1, (unsigned)g.B), dim3(256), lds_win, st, w.res, du,
                                    w.cont, w.ncont, w.ekeys, g.N, g.A, g.L, g.Ns, g.NAT);
             }
-            hipLaunchKernelGGL(select_subtract_kernel, dim3((unsigned)g.B), dim3(256), 0, st, w.ekeys,
-                               (int64_t)(MAXCONT + 1), w.res, rule.du_sub, w.dirty, out_atom, out_lag, out_gain, g.N,
-                               g.L, g.Ns, g.NBLK, K, k, w.cont, w.ncont, w.keys, w.ceps, n_cells, rule.shift,
-                               rule.square);
+            if (b_tail) {
+                MP_FFT_DISPATCH(f.logM, {
+                    constexpr int LB = (LG >= 10 && LG <= 12) ? LG : 10;  // (other sizes never get here)
+                    const size_t lds_b = ((size_t)(1 << LB) + (1 << LB) / 64 + 64) * sizeof(cpx);
+                    if ((rc = fft_lds_attr(fft_select_b_kernel<LB>, lds_b))) return rc;
+                    hipLaunchKernelGGL(fft_select_b_kernel<LB>, dim3((unsigned)g.B), dim3(256), lds_b, st, w.ekeys,
+                                       w.res, rule.du_sub, w.dirty, out_atom, out_lag, out_gain, g.N, g.L, g.Ns, g.NBLK,
+                                       g.NAT, K, k, w.cont, w.ncont, w.keys, w.ceps, rule.shift, rule.square, w.tw,
+                                       w.xspec, w.wnorm, f.NW, rule.square ? w.dscale : (const float *)nullptr);
+                })
+            } else {
+                hipLaunchKernelGGL(select_subtract_kernel, dim3((unsigned)g.B), dim3(256), 0, st, w.ekeys,
+                                   (int64_t)(MAXCONT + 1), w.res, rule.du_sub, w.dirty, out_atom, out_lag, out_gain,
+                                   g.N, g.L, g.Ns, g.NBLK, K, k, w.cont, w.ncont, w.keys, w.ceps, n_cells, rule.shift,
+                                   rule.square);
+            }
         }
         g_prof.end(st);
         HIP_TRY(hipGetLastError());

@@ -11,9 +11,11 @@ rounds = int(sys.argv[2]) if len(sys.argv) > 2 else 5
 A, L, N, B, K = {"c2": (512, 512, 32768, 64, 64), "c4": (4096, 2048, 131072, 16, 16)}[shape]
 # (name, path, flags, tau, screen pairs-per-slot override)
 variants = [("fft", 1, 0, 2e-5, 0), ("fft_prefetch", 1, nat.MP_FLAG_FFT_PREFETCH, 2e-5, 0),
-            ("fft_pps1", 1, 0, 2e-5, 1), ("fft_pps2", 1, 0, 2e-5, 2), ("fft_pps4", 1, 0, 2e-5, 4),
-            ("fft_pps8", 1, 0, 2e-5, 8), ("fft_pf_pps4", 1, nat.MP_FLAG_FFT_PREFETCH, 2e-5, 4),
-            ("fft_fused", 1, nat.MP_FLAG_FFT_FUSED, 2e-5, 0), ("fft_tau5e-6", 1, 0, 5e-6, 0)]
+            ("fft_pps4", 1, 0, 2e-5, 4),
+            ("fft_pps8", 1, 0, 2e-5, 8),
+            ("fft_unfused", 1, nat.MP_FLAG_FFT_UNFUSED, 2e-5, 0), ("fft_fused", 1, nat.MP_FLAG_FFT_FUSED, 2e-5, 0), ("fft_overlap", 1, nat.MP_FLAG_OVERLAP, 2e-5, 0),
+            ("fft_overlap_pps4", 1, nat.MP_FLAG_OVERLAP, 2e-5, 4), ("fft_overlap_pps8", 1, nat.MP_FLAG_OVERLAP, 2e-5, 8),
+            ("fft_unfused_overlap", 1, nat.MP_FLAG_OVERLAP | nat.MP_FLAG_FFT_UNFUSED, 2e-5, 0), ("fft_tau5e-6", 1, 0, 5e-6, 0)]
 if shape == "c2":
     variants += [("incremental", 2, 0, 2e-5, 0)]
 d = synth.make_dictionary(A, L, seed=1000)
