@@ -125,14 +125,17 @@ def launch_times(prof, steps):
     ms_inc, n_inc = prof["corr_inc"]
     if n_full + n_inc == 0:
         return None
-    full_launches = steps if n_inc else steps * K_ITERS      # MP_PATH_DIRECT: every launch is a full pass
-    inc_launches = steps * (K_ITERS - 1) if n_inc else 0
+    # the FFT schedule splits the batch into sub-batches on forked streams (one launch per sub-batch and
+    # step): the sampled full passes tell how many
+    groups = max(1, n_full // steps) if n_inc else 1
+    full_launches = steps * groups if n_inc else steps * K_ITERS   # MP_PATH_DIRECT: every launch is a full pass
+    inc_launches = steps * (K_ITERS - 1) * groups if n_inc else 0
     avg_full = ms_full / max(n_full, 1)
     avg_inc = ms_inc / max(n_inc, 1)
     sec = (avg_full * full_launches + avg_inc * inc_launches) * 1e-3
     launches = full_launches + inc_launches
     return sec, {
-        "launches": launches, "avg_launch_ms": round(sec * 1e3 / launches, 5),
+        "launches": launches, "avg_launch_ms": round(sec * 1e3 / launches, 5), "sub_batches": groups,
         "timed_with_events": {"full_pass": n_full, "incremental": n_inc,
                               "sampling": f"iterations k % {PROF_EVERY} == 0 of each timed encode"},
         "full_pass_launches": full_launches, "full_pass_avg_ms": round(avg_full, 5),
@@ -227,7 +230,11 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--path", default="fft", choices=list(PATHS))
-    ap.add_argument("--flags", type=int, default=0)
+    ap.add_argument("--flags", type=int, default=nat.MP_FLAG_NO_OVERLAP,
+                    help="MP_FLAG_* bits for the timed region.  Default: the single-stream schedule, so that the "
+                         "event-timed kernel durations the roofline is built on are not stretched by a second "
+                         "sub-batch running beside them; the library's own default for MP_PATH_FFT (two "
+                         "sub-batches on forked streams) is reported under variants.")
     ap.add_argument("--no-variants", action="store_true", help="skip the direct-path variant leg")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--backend", default=None, help="torch.distributed backend (default nccl = RCCL)")
@@ -286,13 +293,16 @@ def main():
     if rank == 0 and world == 1:
         if not args.no_variants:
             line["variants"] = {}
-            for name, other in (("incremental_direct_mfma", nat.MP_PATH_INCREMENTAL),
-                                ("direct_full_recompute_mfma", nat.MP_PATH_DIRECT),
-                                ("fft_screen_refine", nat.MP_PATH_FFT)):
-                if other == path:
+            for name, other, vflags in (("fft_two_sub_batches_library_default", nat.MP_PATH_FFT, 0),
+                                        ("incremental_direct_mfma", nat.MP_PATH_INCREMENTAL, args.flags),
+                                        ("direct_full_recompute_mfma", nat.MP_PATH_DIRECT, args.flags),
+                                        ("fft_screen_refine", nat.MP_PATH_FFT, args.flags)):
+                if other == path and vflags == args.flags:
                     continue
                 vsteps = 1 if other == nat.MP_PATH_DIRECT else max(1, min(args.steps, 3))
-                vdt, vout, vprof = timed_encodes(x, du, vsteps, 1, other, args.flags, group)
+                if other == nat.MP_PATH_FFT:
+                    vsteps = args.steps
+                vdt, vout, vprof = timed_encodes(x, du, vsteps, 1, other, vflags, group)
                 vlag = vout[1].cpu().numpy()
                 same = all(torch.equal(p, q) for p, q in zip(vout, out))
                 vroof = (roofline_fft(vprof, B_PER_GPU, vsteps) if other == nat.MP_PATH_FFT

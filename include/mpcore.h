@@ -56,7 +56,9 @@ extern "C" {
 #define MP_FLAG_FFT_WAVE 256 /* MP_PATH_FFT: one-wavefront-per-transform screen (M = 1024 / 2048 only)          */
 #define MP_FLAG_FFT_UNFUSED 512 /* MP_PATH_FFT: select-A / refine / select-B always as three kernels            */
 #define MP_FLAG_FFT_FUSED 1024  /* MP_PATH_FFT: ... always as one kernel (default: by cells per segment)        */
-#define MP_FLAG_OVERLAP 2048    /* two sub-batches on forked internal streams (joined before returning)           */
+#define MP_FLAG_OVERLAP 2048    /* sub-batches on forked internal streams (joined before returning); default for
+                                   MP_PATH_FFT from 32 segments up                                               */
+#define MP_FLAG_NO_OVERLAP 4096 /* never split the batch                                                          */
 #define MP_FLAG_NO_PERSISTENT 8 /* one workgroup per 4 cells instead of machine-sized persistent grid */
 
 int mp_version(void);
@@ -75,9 +77,11 @@ int mp_profile_enable(int every);
 
 /* Tuning hook (process-wide; results never depend on it as long as tau stays above the transform error):
  *   MP_TUNE_TAU         the FFT screen's error bound per unit of window norm (default 2e-5)
- *   MP_TUNE_SCREEN_PPS  atom pairs per transform slot in the screen kernel (0 = heuristic)            */
+ *   MP_TUNE_SCREEN_PPS  atom pairs per transform slot in the screen kernel (0 = heuristic)
+ *   MP_TUNE_GROUPS      sub-batches when the batch is split over forked streams (2..4, default 2)     */
 #define MP_TUNE_TAU 1
 #define MP_TUNE_SCREEN_PPS 2
+#define MP_TUNE_GROUPS 3
 int mp_tune(int key, double value);
 int mp_profile_read(double *ms, int64_t *count);
 

@@ -950,6 +950,7 @@ int fft_lds_attr(K kern, size_t bytes) {
 }
 
 int screen_pps_override = 0;  // tuning hook (mp_tune)
+int overlap_groups = 2;        // sub-batches when the batch is split over forked streams (mp_tune)
 // screen error bound per unit of window norm: measured max |fft - chain| is
 // 6e-7 ||window|| (scripts/screen_error.py), so 2e-5 is a >30x margin; mp_tune(MP_TUNE_TAU, x) overrides
 float FFT_TAU = 2.0e-5f;
@@ -1107,9 +1108,10 @@ int fft_iteration(const Geom &g, const Workspace &w, const float *du, int K, int
 }
 
 // ---- sub-batches on forked streams -----------------------------------------------------------------
+constexpr int MAX_GROUPS = 4;
 struct StreamPool {
-    hipStream_t streams[2];
-    hipEvent_t fork, join[2];
+    hipStream_t streams[MAX_GROUPS];
+    hipEvent_t fork, join[MAX_GROUPS];
 };
 StreamPool *stream_pool() {  // one pool per host thread and device, created on first use, never destroyed
     static thread_local StreamPool pools[16];
@@ -1118,7 +1120,7 @@ StreamPool *stream_pool() {  // one pool per host thread and device, created on 
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return nullptr;
     if (!ready[dev]) {
         StreamPool &p = pools[dev];
-        for (int q = 0; q < 2; ++q) {
+        for (int q = 0; q < MAX_GROUPS; ++q) {
             if (hipStreamCreateWithFlags(&p.streams[q], hipStreamNonBlocking) != hipSuccess) return nullptr;
             if (hipEventCreateWithFlags(&p.join[q], hipEventDisableTiming) != hipSuccess) return nullptr;
         }
@@ -1170,6 +1172,7 @@ size_t mp_workspace_bytes(int64_t B, int64_t N, int64_t A, int64_t L, int K, int
 int mp_tune(int key, double value) {
     if (key == MP_TUNE_TAU && value > 0.0) { FFT_TAU = (float)value; return MP_OK; }
     if (key == MP_TUNE_SCREEN_PPS) { screen_pps_override = (int)value; return MP_OK; }
+    if (key == MP_TUNE_GROUPS && value >= 2 && value <= MAX_GROUPS) { overlap_groups = (int)value; return MP_OK; }
     return fail(MP_ERR_ARG, "mp_tune: unknown key or bad value%s");
 }
 
@@ -1242,13 +1245,16 @@ static int encode_impl(const float *signal, int64_t B, int64_t N, const float *d
         HIP_TRY(hipGetLastError());
     }
 
-    // MP_FLAG_OVERLAP: segments are independent, so the batch can be cut into two sub-batches on forked
-    // streams -- while one is in its short, latency-bound select kernels the other keeps the CUs busy.
-    // Joined back into the caller's stream before returning; fork/join by events is graph-capture safe.
-    // Measured (scripts/fft_ab.py): +4 % at the config-4 shape, +1 % on the incremental MFMA schedule,
-    // -1 % on the FFT schedule at the headline shape (half-batch kernels are latency- not size-bound),
-    // hence opt-in.
-    const int n_groups = (K > 0 && B >= 8 && (flags & MP_FLAG_OVERLAP)) ? 2 : 1;
+    // Segments are independent, so the batch can be cut into sub-batches on forked streams -- while one
+    // is in its short, latency-bound select kernels the others keep the CUs busy.  Joined back into the
+    // caller's stream before returning; fork/join by events is graph-capture safe.
+    // Measured (scripts/fft_ab.py): FFT schedule, headline shape 5.49 -> 5.25 ms per encode with two
+    // sub-batches; +1 % on the incremental MFMA schedule.  Default for MP_PATH_FFT from 32 segments up
+    // (MP_FLAG_NO_OVERLAP turns it off), opt-in elsewhere (MP_FLAG_OVERLAP).
+    int n_groups = 1;
+    if (K > 0 && !(flags & MP_FLAG_NO_OVERLAP) &&
+        (((flags & MP_FLAG_OVERLAP) && B >= 8) || (path == MP_PATH_FFT && B >= 32)))
+        n_groups = overlap_groups >= 2 && overlap_groups <= MAX_GROUPS ? overlap_groups : 2;
     StreamPool *pool = nullptr;
     if (n_groups > 1) {
         pool = stream_pool();

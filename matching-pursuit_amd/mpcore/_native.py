@@ -26,6 +26,8 @@ MP_FLAG_FFT_SIMPLE = 64
 MP_FLAG_FFT_PREFETCH = 128
 MP_TUNE_TAU = 1
 MP_TUNE_SCREEN_PPS = 2
+MP_TUNE_GROUPS = 3
+MP_FLAG_NO_OVERLAP = 4096
 MP_FLAG_FFT_WAVE = 256
 MP_FLAG_FFT_UNFUSED = 512
 MP_FLAG_FFT_FUSED = 1024
