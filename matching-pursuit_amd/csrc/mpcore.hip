@@ -1070,9 +1070,18 @@ int fft_iteration(const Geom &g, const Workspace &w, const float *du, int K, int
                                    w.tw, w.xspec, w.wnorm, f.NW, rule.square ? w.dscale : (const float *)nullptr);
             })
         } else {
-            hipLaunchKernelGGL(fft_select_a_kernel, dim3((unsigned)g.B), dim3(1024), 0, st, w.keys, w.ceps, n_cells,
-                               w.cont, w.ncont, w.ekeys, w.overflow);
-            if (flags & MP_FLAG_REFINE_MFMA) {
+            // select-A merged into the refinement launch when select-B is the kernel that clears the slots
+            // afterwards and a segment's keys are few enough for every workgroup to scan them
+            const bool scan_refine = b_tail && !(flags & (MP_FLAG_REFINE_MFMA | MP_FLAG_FFT_UNFUSED)) && n_cells <= 16384;
+            if (scan_refine) {
+                const size_t lds_win = (size_t)(round_up(g.L, 64) + 128) * sizeof(float);
+                hipLaunchKernelGGL(fft_scan_refine_kernel, dim3((unsigned)g.B, 8), dim3(256), lds_win, st, w.keys, w.ceps,
+                                   n_cells, w.res, du, w.cont, w.ncont, w.ekeys, w.overflow, g.N, g.A, g.L, g.Ns, g.NAT);
+            } else
+                hipLaunchKernelGGL(fft_select_a_kernel, dim3((unsigned)g.B), dim3(1024), 0, st, w.keys, w.ceps, n_cells,
+                                   w.cont, w.ncont, w.ekeys, w.overflow);
+            if (scan_refine) {
+            } else if (flags & MP_FLAG_REFINE_MFMA) {
                 if (dma)
                     hipLaunchKernelGGL(fft_refine_kernel<true>, dim3((unsigned)g.B, 4), dim3(256), lds_ref, st, w.res,
                                        w.img, w.cont, w.ncont, w.ekeys, g.N, g.A, g.Ns, g.NBLK, g.NAT, g.KC, g.NCH);
