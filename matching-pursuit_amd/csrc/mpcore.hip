@@ -1075,7 +1075,7 @@ int fft_iteration(const Geom &g, const Workspace &w, const float *du, int K, int
             const bool scan_refine = b_tail && !(flags & (MP_FLAG_REFINE_MFMA | MP_FLAG_FFT_UNFUSED)) && n_cells <= 16384;
             if (scan_refine) {
                 const size_t lds_win = (size_t)(round_up(g.L, 64) + 128) * sizeof(float);
-                hipLaunchKernelGGL(fft_scan_refine_kernel, dim3((unsigned)g.B, 8), dim3(256), lds_win, st, w.keys, w.ceps,
+                hipLaunchKernelGGL(fft_scan_refine_kernel, dim3((unsigned)g.B, 8), dim3(SR_WG), lds_win, st, w.keys, w.ceps,
                                    n_cells, w.res, du, w.cont, w.ncont, w.ekeys, w.overflow, g.N, g.A, g.L, g.Ns, g.NAT);
             } else
                 hipLaunchKernelGGL(fft_select_a_kernel, dim3((unsigned)g.B), dim3(1024), 0, st, w.keys, w.ceps, n_cells,
