@@ -1038,16 +1038,18 @@ int fft_iteration(const Geom &g, const Workspace &w, const float *du, int K, int
                 while (pps > 1 && tasks * (16 / (C::SLOTS * pps)) < 8 * (int64_t)num_cus()) pps >>= 1;
                 if (screen_pps_override > 0 && 16 % (C::SLOTS * screen_pps_override) == 0) pps = screen_pps_override;
                 const size_t lds_s = ((size_t)C::SLOTS * C::M + C::M / 64 + 64) * sizeof(cpx);
+                // pair spectra that cannot stay in the L2s: segment-fastest grid order (see the kernel)
+                const bool seg_fast = (size_t)g.NAT * f.NPT * f.M * sizeof(cpx) > (size_t)16 << 20;
+                const unsigned gwp = nw * (16 / (C::SLOTS * pps));
+                const dim3 grid = seg_fast ? dim3((unsigned)g.B, gwp, g.NAT) : dim3(gwp, g.NAT, (unsigned)g.B);
                 if (flags & MP_FLAG_FFT_PREFETCH) {
                     if ((rc = fft_lds_attr(fft_screen_kernel<LS, true>, lds_s))) return rc;
-                    hipLaunchKernelGGL((fft_screen_kernel<LS, true>), dim3(nw * (16 / (C::SLOTS * pps)), g.NAT, (unsigned)g.B),
-                                       dim3(C::WG), lds_s, st, w.xspec, w.pspec, w.tw, dirty, w.wnorm, w.keys, w.ceps,
-                                       g.N, g.A, g.NBLK, g.NAT, f.V, f.NW, FFT_TAU, pps);
+                    hipLaunchKernelGGL((fft_screen_kernel<LS, true>), grid, dim3(C::WG), lds_s, st, w.xspec, w.pspec, w.tw,
+                                       dirty, w.wnorm, w.keys, w.ceps, g.N, g.A, g.NBLK, g.NAT, f.V, f.NW, FFT_TAU, pps, (int)seg_fast);
                 } else {
                     if ((rc = fft_lds_attr(fft_screen_kernel<LS, false>, lds_s))) return rc;
-                    hipLaunchKernelGGL((fft_screen_kernel<LS, false>), dim3(nw * (16 / (C::SLOTS * pps)), g.NAT, (unsigned)g.B),
-                                       dim3(C::WG), lds_s, st, w.xspec, w.pspec, w.tw, dirty, w.wnorm, w.keys, w.ceps,
-                                       g.N, g.A, g.NBLK, g.NAT, f.V, f.NW, FFT_TAU, pps);
+                    hipLaunchKernelGGL((fft_screen_kernel<LS, false>), grid, dim3(C::WG), lds_s, st, w.xspec, w.pspec, w.tw,
+                                       dirty, w.wnorm, w.keys, w.ceps, g.N, g.A, g.NBLK, g.NAT, f.V, f.NW, FFT_TAU, pps, (int)seg_fast);
                 }
             } else {
                 hipLaunchKernelGGL(fft_correlate_kernel<LG>, dim3(nw, g.NAT, (unsigned)g.B), dim3(256), lds, st,
@@ -1258,11 +1260,13 @@ static int encode_impl(const float *signal, int64_t B, int64_t N, const float *d
     // is in its short, latency-bound select kernels the others keep the CUs busy.  Joined back into the
     // caller's stream before returning; fork/join by events is graph-capture safe.
     // Measured (scripts/fft_ab.py): FFT schedule, headline shape 5.49 -> 5.25 ms per encode with two
-    // sub-batches; +1 % on the incremental MFMA schedule.  Default for MP_PATH_FFT from 32 segments up
+    // sub-batches; +1 % on the incremental MFMA schedule; -4 % at the config-4 shape, whose screens fill the
+    // GPU on their own.  Default for MP_PATH_FFT from 32 segments up when a segment has < 65536 cells
     // (MP_FLAG_NO_OVERLAP turns it off), opt-in elsewhere (MP_FLAG_OVERLAP).
     int n_groups = 1;
     if (K > 0 && !(flags & MP_FLAG_NO_OVERLAP) &&
-        (((flags & MP_FLAG_OVERLAP) && B >= 8) || (path == MP_PATH_FFT && B >= 32)))
+        (((flags & MP_FLAG_OVERLAP) && B >= 8) ||
+         (path == MP_PATH_FFT && B >= 32 && (int64_t)g.NBLK * g.NAT < 65536)))  // big screens fill the GPU alone
         n_groups = overlap_groups >= 2 && overlap_groups <= MAX_GROUPS ? overlap_groups : 2;
     StreamPool *pool = nullptr;
     if (n_groups > 1) {

@@ -16,17 +16,25 @@ print(f"inputs generated in {time.time() - t0:.1f} s", flush=True)
 xd = torch.from_numpy(x).cuda()
 du = nat.unit_norm(torch.from_numpy(d).cuda())
 nat.encode(xd[:4], du, 2, path=nat.MP_PATH_FFT); torch.cuda.synchronize()
-nat.profile_enable(True); nat.profile_read()
-t0 = time.perf_counter()
-atom, lag, gain, res = nat.encode(xd, du, K, path=nat.MP_PATH_FFT)
-torch.cuda.synchronize()
-dt = time.perf_counter() - t0
-p = nat.profile_read()
-print(f"c4 full: B{B} K{K}: {dt:.3f} s -> {B * K / dt:.0f} seg-it/s; overflow segments: {int(torch.isnan(gain).any(dim=1).sum())}", flush=True)
-print({k: (round(v[0] / max(v[1], 1), 3), v[1]) for k, v in p.items()}, "ms avg, launches", flush=True)
 M = 8192
 spectra_bytes = (A // 2 + 1) * 8.0 * M
-print(f"screen: algorithmic spectra per incremental launch {B * spectra_bytes / 1e9:.2f} GB -> {B * spectra_bytes / (p['corr_inc'][0] / p['corr_inc'][1] * 1e-3) / 1e12:.2f} TB/s", flush=True)
+for name, flags, every in (("one stream, events around every launch", nat.MP_FLAG_NO_OVERLAP, 1),
+                           ("one stream", nat.MP_FLAG_NO_OVERLAP, 16),
+                           ("two sub-batches on forked streams (library default)", 0, 16)):
+    nat.profile_enable(every); nat.profile_read()
+    t0 = time.perf_counter()
+    atom, lag, gain, res = nat.encode(xd, du, K, path=nat.MP_PATH_FFT, flags=flags)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    p = nat.profile_read()
+    print(f"c4 full, {name}: B{B} K{K}: {dt:.3f} s -> {B * K / dt:.0f} seg-it/s; overflow segments: "
+          f"{int(torch.isnan(gain).any(dim=1).sum())}", flush=True)
+    print("  ", {k: (round(v[0] / max(v[1], 1), 3), v[1]) for k, v in p.items()}, "ms avg, spans", flush=True)
+    if flags:
+        inc = p['corr_inc'][0] / p['corr_inc'][1] * 1e-3
+        print(f"   screen: algorithmic spectra per incremental launch {B * spectra_bytes / 1e9:.2f} GB -> "
+              f"{B * spectra_bytes / inc / 1e12:.2f} TB/s", flush=True)
+nat.profile_enable(0)
 rec = torch.zeros_like(xd)
 nat.scatter(atom, torch.arange(B, device="cuda")[:, None].expand(B, K), lag, gain, du, rec)
 print("round trip max err", float((rec + res - xd).abs().max()), "residual dB", float(20 * torch.log10(res.norm() / xd.norm())), flush=True)
