@@ -1,0 +1,19 @@
+#!/usr/bin/env python3
+"""A short FFT-schedule run at the BASELINE configs[3] shape, for rocprofv3 --pmc passes (fabric traffic of
+the screen kernel when the pair spectra no longer fit the L2s):  c4_traffic.py [B] [K]"""
+import os, sys
+import torch
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(REPO, "matching-pursuit_amd"))
+from mpcore import _native as nat
+from mpcore import synth
+A, L, N = 4096, 2048, 131072
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 128
+K = int(sys.argv[2]) if len(sys.argv) > 2 else 6
+d = synth.make_dictionary(A, L, seed=4000)
+x = synth.make_segments(B, N, d, n_events=64, seed=4001)
+xd = torch.from_numpy(x).cuda()
+du = nat.unit_norm(torch.from_numpy(d).cuda())
+out = nat.encode(xd, du, K, path=nat.MP_PATH_FFT, flags=nat.MP_FLAG_NO_OVERLAP)
+torch.cuda.synchronize()
+print("done", int(torch.isnan(out[2]).any()), flush=True)
