@@ -441,31 +441,95 @@ def dictionary_learning_step(
 # --------------------------------------------------------------------------------------------
 # sparse_feature_map / sparse_coding_loss  (modules/matchingpursuit.py:68-146, 422-463)
 # --------------------------------------------------------------------------------------------
+class _SparseFeatureMapFn(torch.autograd.Function):
+    """sparse_feature_map with the reference's gradient (modules/matchingpursuit.py:100-120).
+
+    Forward: the K events come from the native encoder; the dense map holds each step's value at its argmax.
+    Backward: what autograd does to the reference's loop, step by step from the last to the first:
+
+        fm      += hard_i * f_i,   hard_i = softmax(f_i) + (onehot_i - softmax(f_i)).detach()     (sparse.py:29-43)
+        r_{i+1}  = r_i - v_i * d[a_i] at p_i (cropped at N),   v_i = f_i[a_i, p_i]                (:103-120)
+
+    With G the gradient arriving at fm and lam the gradient w.r.t. r_{i+1}:
+        w      = s * (G f_i - <G f_i, s>)                 (through the softmax, s = softmax(f_i) over A*N)
+        w[a_i, p_i] += G[a_i, p_i] - <lam[p_i : p_i+L], d[a_i]>     (through hard's value 1 and through v_i)
+        lam    = lam + conv_transpose(w, d)[:N]
+    f_i is recomputed densely per step by the native kernel (mp_feature_map_f32) from r_i, which is
+    replayed backwards from the final residual; softmax and the transposed convolution are tensor ops.
+    This costs K dense passes -- as the reference's own forward does."""
+
+    @staticmethod
+    def forward(ctx, x, d_unit, n_steps):
+        # x [B, N] on the compute device
+        atom, lag, gain, residual = _native.encode_checked(x.detach(), d_unit, n_steps)
+        B, N = x.shape
+        A = d_unit.shape[0]
+        fm = torch.zeros(B, A, N, device=x.device)
+        if n_steps > 0:
+            bidx = torch.arange(B, device=x.device)[:, None].expand_as(atom)
+            fm.index_put_((bidx.reshape(-1), atom.reshape(-1), lag.reshape(-1)), gain.reshape(-1), accumulate=True)
+        ctx.save_for_backward(d_unit, atom, lag, gain, residual)
+        ctx.mark_non_differentiable(atom, lag)
+        return fm, residual, atom, lag, gain.clone()
+
+    @staticmethod
+    def backward(ctx, g_fm, g_res, _ga, _gl, _gg):
+        d_unit, atom, lag, gain, r = ctx.saved_tensors
+        B, N = r.shape
+        A, L = d_unit.shape
+        K = atom.shape[1]
+        dev = r.device
+        j = torch.arange(L, device=dev)
+        bidx = torch.arange(B, device=dev)
+        lam = g_res.clone() if g_res is not None else torch.zeros(B, N, device=dev)
+        g_fm = g_fm if g_fm is not None else torch.zeros(B, A, N, device=dev)
+        r = r.clone()
+        for i in range(K - 1, -1, -1):
+            a, p, v = atom[:, i], lag[:, i], gain[:, i]
+            da = d_unit[a]                                             # [B, L]
+            pos = p[:, None] + j[None, :]
+            ok = pos < N
+            posc = pos.clamp(max=N - 1)
+            r.scatter_add_(1, posc, torch.where(ok, v[:, None] * da, torch.zeros_like(da)))   # r_i
+            f = _native.feature_map(r, d_unit)                         # [B, A, N], exact chains
+            s = torch.softmax(f.reshape(B, -1), dim=-1).reshape(B, A, N)
+            gf = g_fm * f
+            c = (gf * s).sum(dim=(1, 2), keepdim=True)
+            w = s * (gf - c)
+            lam_win = torch.where(ok, lam.gather(1, posc), torch.zeros_like(da))
+            w[bidx, a, p] += g_fm[bidx, a, p] - (lam_win * da).sum(-1)
+            lam = lam + F.conv_transpose1d(w, d_unit.view(A, 1, L))[:, 0, :N]
+        return lam, None, None
+
+
 def sparse_feature_map(signal, d, n_steps=100, device=None, approx=None, pooling=None,
                        return_residual=False):
-    """Forward values of :68-125: the dense [B, A, N] map holding, per step, the feature-map
-    value at that step's argmax (soft_dirac's forward is the one-hot of the argmax, :100-101).
-    Built from the encoder's events; no softmax over A*N per step."""
+    """modules/matchingpursuit.py:68-125: the dense [B, A, N] map holding, per step, the feature-map value at
+    that step's argmax (soft_dirac's forward is the one-hot of the argmax, :100-101).  Built from the encoder's
+    events -- no softmax over A*N per step in the forward; differentiable w.r.t. the signal like the
+    reference (see _SparseFeatureMapFn)."""
     signal = signal.view(signal.shape[0], 1, -1)
     batch, _, n_samples = signal.shape
     n_atoms, atom_size = d.shape
     out_dev = signal.device
     dev = _compute_device(signal)
-    if signal.requires_grad:
-        raise NotImplementedError(
-            "mpcore.sparse_feature_map: gradients w.r.t. the signal are not implemented yet")
     d_unit = _native.unit_norm(d.detach().to(dev))
     approximate = isinstance(approx, slice) or (
         isinstance(approx, int) and not isinstance(approx, bool) and approx < n_samples)
     if approximate:
+        if signal.requires_grad:
+            raise NotImplementedError(
+                "mpcore.sparse_feature_map: gradients through the approximate (band-limited) correlation "
+                "are not implemented")
         atom, lag, gain, residual, _ = _sparse_code_dense(signal.to(dev), d_unit, n_steps, approx, None, None,
                                                           False, None)
+        fm = torch.zeros(batch, n_atoms, n_samples, device=dev)
+        if n_steps > 0:
+            bidx = torch.arange(batch, device=dev)[:, None].expand_as(atom)
+            fm.index_put_((bidx.reshape(-1), atom.reshape(-1), lag.reshape(-1)), gain.reshape(-1), accumulate=True)
     else:
-        atom, lag, gain, residual = _native.encode_checked(signal.to(dev)[:, 0, :], d_unit, n_steps)
-    fm = torch.zeros(batch, n_atoms, n_samples, device=dev)
-    if n_steps > 0:
-        bidx = torch.arange(batch, device=dev)[:, None].expand_as(atom)
-        fm.index_put_((bidx.reshape(-1), atom.reshape(-1), lag.reshape(-1)), gain.reshape(-1), accumulate=True)
+        x = signal.to(dev, torch.float32)[:, 0, :]
+        fm, residual, _, _, _ = _SparseFeatureMapFn.apply(x, d_unit, n_steps)
     fm = fm.to(out_dev)
     if return_residual:
         return fm, residual.view(batch, 1, n_samples).to(out_dev)

@@ -168,9 +168,17 @@ def main():
         fm, res = mp.sparse_feature_map(torch.from_numpy(x), torch.from_numpy(d), n_steps=6,
                                         return_residual=True)
     nz = torch.nonzero(fm)
+    # ... and its gradient w.r.t. the signal (through hard * f and through the subtraction, :100-120) for the
+    # loss <fm, W> + <residual, V> with W, V from numpy's PCG64(55) (the test redraws them)
+    rng = np.random.default_rng(55)
+    W = rng.standard_normal((2, 16, 1024)).astype(np.float32)
+    V = rng.standard_normal((2, 1, 1024)).astype(np.float32)
+    xs = torch.from_numpy(x).clone().requires_grad_(True)
+    fm_g, res_g = mp.sparse_feature_map(xs, torch.from_numpy(d), n_steps=6, return_residual=True)
+    ((fm_g * torch.from_numpy(W)).sum() + (res_g * torch.from_numpy(V)).sum()).backward()
     np.savez_compressed(os.path.join(HERE, "sparse_feature_map.npz"), signal=x, d_raw=d,
                         nz_index=nz.numpy(), nz_value=fm[nz[:, 0], nz[:, 1], nz[:, 2]].numpy(),
-                        residual=res.numpy()[:, 0, :], n_steps=np.int64(6))
+                        residual=res.numpy()[:, 0, :], n_steps=np.int64(6), grad_signal=xs.grad.numpy())
 
     # iterative_loss (modules/iterative.py:24-74) with the stft transform
     # (iterativedecomposition.py:81-86 uses stft(x, 2048, 256, pad=True))

@@ -151,6 +151,27 @@ def test_sparse_feature_map_matches_reference(golden_dir):
     assert torch.isfinite(loss)
 
 
+def test_sparse_feature_map_gradient_matches_reference(golden_dir):
+    """d/d signal of <fm, W> + <residual, V> against the reference's autograd (through soft_dirac's
+    straight-through softmax, :100-101, and through the subtraction, :103-120)."""
+    z = np.load(os.path.join(golden_dir, "sparse_feature_map.npz"))
+    rng = np.random.default_rng(55)   # as tests/golden/generate_golden.py draws them
+    W = torch.from_numpy(rng.standard_normal((2, 16, 1024)).astype(np.float32)).to(DEV)
+    V = torch.from_numpy(rng.standard_normal((2, 1, 1024)).astype(np.float32)).to(DEV)
+    d = torch.from_numpy(z["d_raw"]).to(DEV)
+    x = torch.from_numpy(z["signal"]).to(DEV).requires_grad_(True)
+    fm, res = mp.sparse_feature_map(x, d, n_steps=int(z["n_steps"]), return_residual=True)
+    ((fm * W).sum() + (res * V).sum()).backward()
+    want = z["grad_signal"]
+    got = x.grad.cpu().numpy()
+    assert got.shape == want.shape
+    assert np.abs(got - want).max() <= 2e-4 * np.abs(want).max()
+    # the loss built on it is differentiable w.r.t. the reconstruction, as callers expect (:128-146)
+    recon = (torch.from_numpy(z["signal"]).to(DEV) * 0.9).requires_grad_(True)
+    mp.sparse_coding_loss(recon, torch.from_numpy(z["signal"]).to(DEV), d, n_steps=3).backward()
+    assert recon.grad is not None and torch.isfinite(recon.grad).all() and recon.grad.abs().sum() > 0
+
+
 def test_unit_norm_and_conv_wrappers(golden_dir):
     import modules
     import modules.conv as conv
