@@ -6,3 +6,4 @@ from .matchingpursuit import (  # noqa: F401
     sparse_feature_map, sparse_coding_loss, SparseCodingLoss, unit_norm, torch_conv, fft_convolve,
     EventList, encode_packed)
 from .iterative import iterative_loss, sort_channels_descending_norm  # noqa: F401
+from .streaming import encode_streaming, decode_streaming, StreamCode  # noqa: F401

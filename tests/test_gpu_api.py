@@ -320,3 +320,39 @@ def test_key_points_match_reference(golden_dir):
     assert np.abs(rnorm.cpu().numpy() - z["residual_norm"]).max() <= 1e-5 * z["residual_norm"].max()
     with pytest.raises(RuntimeError):  # n_atoms != atom_size cannot be viewed, as in the reference (:215)
         mp.sparse_code_to_differentiable_key_points(torch.zeros(1, 256, device=DEV), torch.rand(8, 16, device=DEV), 2)
+
+
+@pytest.mark.parametrize("order", ["sequential", "even_odd"])
+def test_streaming_encode_carries_the_residual(oracle, order):
+    """Long audio in windows of one segment at a 50 % hop: every window is encoded on what
+    the earlier windows left -- checked window by window against the oracle run in the same order -- and
+    decode(events) + residual gives the audio back."""
+    from mpcore import streaming
+    A, L, window, hop, K, B, T = 24, 128, 2048, 1024, 6, 2, 5000
+    d = synth.make_dictionary(A, L, seed=77)
+    audio = synth.make_segments(B, T, d, n_events=30, seed=78)
+    code = streaming.encode_streaming(torch.from_numpy(audio).to(DEV), torch.from_numpy(d).to(DEV), window, hop, K,
+                                      order=order)
+    W = streaming.n_windows(T, window, hop)
+    assert code.atom.shape == (B, W, K) and code.residual.shape == (B, T) and W == 4
+    # the same walk on the CPU oracle
+    du = oracle.unit_norm(d)
+    padded = (W - 1) * hop + window
+    res = np.zeros((B, padded), dtype=np.float32)
+    res[:, :T] = audio
+    walk = range(W) if order == "sequential" else [w for par in (0, 1) for w in range(par, W, 2)]
+    for w in walk:
+        s = w * hop
+        want = oracle.encode(np.ascontiguousarray(res[:, s:s + window]), du, K)
+        res[:, s:s + window] = want["residual"]
+        assert np.array_equal(code.atom[:, w].cpu().numpy(), want["atom"]), (order, w)
+        assert np.array_equal(code.position[:, w].cpu().numpy(), want["lag"] + s), (order, w)
+        assert np.array_equal(code.gain[:, w].cpu().numpy(), want["gain"]), (order, w)
+    assert np.array_equal(code.residual.cpu().numpy(), res[:, :T])
+    rec = streaming.decode_streaming(code)
+    scale = np.abs(audio).max()
+    assert np.abs(rec.cpu().numpy() + code.residual.cpu().numpy() - audio).max() <= 1e-5 * scale
+    assert np.linalg.norm(code.residual.cpu().numpy()) < np.linalg.norm(audio)
+    with pytest.raises(ValueError):
+        streaming.encode_streaming(torch.zeros(1, 100, device=DEV), torch.rand(4, 16, device=DEV), 64, 16, 2,
+                                   order="even_odd")
