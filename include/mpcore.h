@@ -58,6 +58,8 @@ extern "C" {
 #define MP_FLAG_FFT_FUSED 1024  /* MP_PATH_FFT: ... always as one kernel (default: by cells per segment)        */
 #define MP_FLAG_OVERLAP 2048    /* sub-batches on forked internal streams (joined before returning); default for
                                    MP_PATH_FFT from 32 segments up                                               */
+#define MP_FLAG_FFT_NO_QUARTER 8192 /* MP_PATH_FFT: small segments through scan+refine / select-B instead of the
+                                       one-kernel quarter-cell select                                           */
 #define MP_FLAG_NO_OVERLAP 4096 /* never split the batch                                                          */
 #define MP_FLAG_NO_PERSISTENT 8 /* one workgroup per 4 cells instead of machine-sized persistent grid */
 

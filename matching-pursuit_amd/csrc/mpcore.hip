@@ -84,6 +84,7 @@ constexpr int LAGS_PER_WAVE = 64;   // one cell = TA atoms x 64 lags, owned by o
 constexpr int WAVES = 4;            // wavefronts per workgroup
 constexpr int KC_MAX = 512;         // atom samples staged in LDS per chunk
 constexpr int MAXCONT = 32;         // FFT path: inexact contender cells per segment per iteration
+constexpr int64_t QUARTER_MAX_CELLS = 16384;  // FFT path: segments this small use the quarter-cell select kernel
 
 __host__ __device__ inline int64_t round_up(int64_t x, int64_t m) { return (x + m - 1) / m * m; }
 
@@ -724,6 +725,7 @@ struct Workspace {
     float *wnorm, *ceps;
     int *cont, *ncont, *overflow;
     float *dscale;  // max atom norm (convolution model: atoms are not unit norm)
+    float *subk;    // per-quarter-cell screen maxima [B][cells][SUBCELLS]; only for <= QUARTER_MAX_CELLS
     u64 *ekeys;
     size_t bytes;
 };
@@ -748,6 +750,7 @@ Workspace carve(const Geom &g, int path, char *base) {
     w.cont = w.ncont = w.overflow = nullptr;
     w.ekeys = nullptr;
     w.dscale = nullptr;
+    w.subk = nullptr;
     if (path == MP_PATH_FFT) {
         FftGeom f;
         if (make_fft_geom(g, &f)) {
@@ -761,6 +764,8 @@ Workspace carve(const Geom &g, int path, char *base) {
             size_t o_ov = take((size_t)g.B * sizeof(int));
             size_t o_ek = take((size_t)g.B * (MAXCONT + 1) * sizeof(u64));
             size_t o_ds = take(256);
+            const bool quarters = (int64_t)g.NBLK * g.NAT <= QUARTER_MAX_CELLS;
+            size_t o_sk = take(quarters ? (size_t)g.B * g.NBLK * g.NAT * SUBCELLS * sizeof(float) : 0);
             w.tw = reinterpret_cast<cpx *>(base + o_tw);
             w.pspec = reinterpret_cast<cpx *>(base + o_ps);
             w.xspec = reinterpret_cast<cpx *>(base + o_xs);
@@ -771,6 +776,7 @@ Workspace carve(const Geom &g, int path, char *base) {
             w.overflow = reinterpret_cast<int *>(base + o_ov);
             w.ekeys = reinterpret_cast<u64 *>(base + o_ek);
             w.dscale = reinterpret_cast<float *>(base + o_ds);
+            if (quarters) w.subk = reinterpret_cast<float *>(base + o_sk);
         }
     }
     w.res = reinterpret_cast<float *>(base + o_res);
@@ -1003,8 +1009,13 @@ int fft_iteration(const Geom &g, const Workspace &w, const float *du, int K, int
                        ((flags & MP_FLAG_FFT_FUSED) || n_cells >= 65536);
     // both forms leave the next step's window spectrum behind when the screen's register transform exists
     // for this size (the stand-alone window kernel then runs before the first step only)
-    const bool b_tail = !fused && !(flags & MP_FLAG_FFT_SIMPLE) && f.logM >= 10 && f.logM <= 12;
-    const bool fused_tail = (fused && f.logM >= 10) || b_tail;
+    // ... or, for small segments, ONE kernel that refines only a quarter of a contender cell (needs the screen's
+    // per-quarter maxima, hence its register transform at pps = 4)
+    const bool quarter = w.subk && f.logM >= 10 &&
+                         !(flags & (MP_FLAG_REFINE_MFMA | MP_FLAG_FFT_UNFUSED | MP_FLAG_FFT_FUSED | MP_FLAG_FFT_SIMPLE |
+                                    MP_FLAG_FFT_WAVE | MP_FLAG_FFT_NO_QUARTER));
+    const bool b_tail = !fused && !quarter && !(flags & MP_FLAG_FFT_SIMPLE) && f.logM >= 10 && f.logM <= 12;
+    const bool fused_tail = (fused && f.logM >= 10) || b_tail || quarter;
     {
         const int *dirty = k == 0 ? nullptr : w.dirty;
         const int nw = k == 0 ? f.NW : 1;
@@ -1037,6 +1048,8 @@ int fft_iteration(const Geom &g, const Workspace &w, const float *du, int K, int
                 const int64_t tasks = (int64_t)nw * g.NAT * g.B;
                 while (pps > 1 && tasks * (16 / (C::SLOTS * pps)) < 8 * (int64_t)num_cus()) pps >>= 1;
                 if (screen_pps_override > 0 && 16 % (C::SLOTS * screen_pps_override) == 0) pps = screen_pps_override;
+                if (quarter) pps = 4;  // one slot = one quarter of a tile
+                float *subk = quarter ? w.subk : nullptr;
                 const size_t lds_s = ((size_t)C::SLOTS * C::M + C::M / 64 + 64) * sizeof(cpx);
                 // pair spectra that cannot stay in the L2s: segment-fastest grid order (see the kernel)
                 const bool seg_fast = (size_t)g.NAT * f.NPT * f.M * sizeof(cpx) > (size_t)16 << 20;
@@ -1045,11 +1058,11 @@ int fft_iteration(const Geom &g, const Workspace &w, const float *du, int K, int
                 if (flags & MP_FLAG_FFT_PREFETCH) {
                     if ((rc = fft_lds_attr(fft_screen_kernel<LS, true>, lds_s))) return rc;
                     hipLaunchKernelGGL((fft_screen_kernel<LS, true>), grid, dim3(C::WG), lds_s, st, w.xspec, w.pspec, w.tw,
-                                       dirty, w.wnorm, w.keys, w.ceps, g.N, g.A, g.NBLK, g.NAT, f.V, f.NW, FFT_TAU, pps, (int)seg_fast);
+                                       dirty, w.wnorm, w.keys, w.ceps, g.N, g.A, g.NBLK, g.NAT, f.V, f.NW, FFT_TAU, pps, (int)seg_fast, subk);
                 } else {
                     if ((rc = fft_lds_attr(fft_screen_kernel<LS, false>, lds_s))) return rc;
                     hipLaunchKernelGGL((fft_screen_kernel<LS, false>), grid, dim3(C::WG), lds_s, st, w.xspec, w.pspec, w.tw,
-                                       dirty, w.wnorm, w.keys, w.ceps, g.N, g.A, g.NBLK, g.NAT, f.V, f.NW, FFT_TAU, pps, (int)seg_fast);
+                                       dirty, w.wnorm, w.keys, w.ceps, g.N, g.A, g.NBLK, g.NAT, f.V, f.NW, FFT_TAU, pps, (int)seg_fast, subk);
                 }
             } else {
                 hipLaunchKernelGGL(fft_correlate_kernel<LG>, dim3(nw, g.NAT, (unsigned)g.B), dim3(256), lds, st,
@@ -1060,7 +1073,18 @@ int fft_iteration(const Geom &g, const Workspace &w, const float *du, int K, int
         g_prof.end(st);
         HIP_TRY(hipGetLastError());
         g_prof.begin(PROF_SELECT, st);
-        if (fused) {
+        if (quarter) {
+            const size_t lds_chain = (size_t)(round_up(g.L, 64) + 128) * sizeof(float);
+            MP_FFT_DISPATCH(f.logM, {
+                constexpr int LQ = LG >= 10 ? LG : 10;  // (smaller sizes never get here)
+                const size_t lds_q = lds_chain + ((size_t)f.M + f.M / 64 + 64) * sizeof(cpx);
+                if ((rc = fft_lds_attr(fft_select_quarter_kernel<LQ>, lds_q))) return rc;
+                hipLaunchKernelGGL(fft_select_quarter_kernel<LQ>, dim3((unsigned)g.B), dim3(1024), lds_q, st, w.keys,
+                                   w.ceps, w.subk, n_cells, w.res, du, w.dirty, w.overflow, out_atom, out_lag, out_gain,
+                                   g.N, g.A, g.L, g.Ns, g.NBLK, g.NAT, K, k, rule.du_sub, rule.shift, rule.square, w.tw,
+                                   w.xspec, w.wnorm, f.NW, rule.square ? w.dscale : (const float *)nullptr);
+            })
+        } else if (fused) {
             const size_t lds_chain = (size_t)(round_up(g.L, 64) + 128) * sizeof(float);
             MP_FFT_DISPATCH(f.logM, {
                 constexpr int LT = LG >= 10 ? LG : 0;                  // 0: no tail transform
@@ -1157,6 +1181,7 @@ Workspace sub_batch(const Workspace &w, const Geom &g, int path, int64_t b0, int
         v.ncont = w.ncont + b0;
         v.overflow = w.overflow + b0;
         v.ekeys = w.ekeys + b0 * (MAXCONT + 1);
+        if (w.subk) v.subk = w.subk + b0 * cells * SUBCELLS;
     }
     return v;
 }

@@ -32,6 +32,8 @@ PATHS = [
     ("incremental_overlap", nat.MP_PATH_INCREMENTAL, nat.MP_FLAG_OVERLAP),
     ("fft_unfused", nat.MP_PATH_FFT, nat.MP_FLAG_FFT_UNFUSED),
     ("fft_fused", nat.MP_PATH_FFT, nat.MP_FLAG_FFT_FUSED),
+    ("fft_scan_refine", nat.MP_PATH_FFT, nat.MP_FLAG_FFT_NO_QUARTER),
+    ("fft_one_stream", nat.MP_PATH_FFT, nat.MP_FLAG_NO_OVERLAP),
     ("fft_wave", nat.MP_PATH_FFT, nat.MP_FLAG_FFT_WAVE),
     ("fft_simple", nat.MP_PATH_FFT, nat.MP_FLAG_FFT_SIMPLE),
     ("fft_prefetch", nat.MP_PATH_FFT, nat.MP_FLAG_FFT_PREFETCH),
