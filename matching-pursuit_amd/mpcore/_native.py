@@ -135,7 +135,8 @@ def workspace_bytes(B, N, A, L, K, path):
     return int(n)
 
 
-FFT_MAX_ATOM = 5398  # longest atom whose 3L+190-point transform fits one workgroup's LDS
+FFT_MAX_ATOM = 5398     # longest atom whose 3L+190-point transform fits one workgroup's LDS
+FFT_MAX_BATCH = 65535   # segments per mp_encode_f32 call on MP_PATH_FFT (the wrapper chunks larger batches)
 
 
 def default_path(n_atom_samples):
@@ -179,6 +180,15 @@ def encode(signal, dict_unit, n_steps, path=MP_PATH_INCREMENTAL, flags=0, want_r
     gain = torch.empty((B, K), dtype=torch.float32, device=dev)
     residual = torch.empty((B, N), dtype=torch.float32, device=dev) if want_residual else None
     if B == 0:
+        return atom, lag, gain, residual
+    if path == MP_PATH_FFT and B > FFT_MAX_BATCH:  # one grid dimension of the screen is the batch: chunk it
+        for b0 in range(0, B, FFT_MAX_BATCH):
+            sl = slice(b0, min(b0 + FFT_MAX_BATCH, B))
+            a, l, g, r = encode(signal[sl], dict_unit, K, path=path, flags=flags, want_residual=want_residual,
+                                conv_model=conv_model)
+            atom[sl], lag[sl], gain[sl] = a, l, g
+            if want_residual:
+                residual[sl] = r
         return atom, lag, gain, residual
     nbytes = workspace_bytes(B, N, A, L, K, path)
     ws = torch.empty(nbytes + 256, dtype=torch.uint8, device=dev)

@@ -294,3 +294,15 @@ def test_c2_golden_shape_vs_oracle_bitwise(oracle, c2_inputs):
     want = oracle.encode(x[:2].cpu().numpy(), du.cpu().numpy(), K)
     assert np.array_equal(atom, want["atom"]) and np.array_equal(lag, want["lag"])
     assert np.array_equal(gain, want["gain"]) and np.array_equal(residual, want["residual"])
+
+
+def test_fft_batches_above_the_per_call_limit_are_chunked(monkeypatch):
+    """MP_PATH_FFT takes at most 65535 segments per call (a grid dimension); the binding cuts larger batches."""
+    d = synth.make_dictionary(16, 48, seed=21)
+    x = synth.make_segments(7, 900, d, n_events=9, seed=22)
+    xd = torch.from_numpy(x).to(DEV)
+    du = nat.unit_norm(torch.from_numpy(d).to(DEV))
+    whole = nat.encode(xd, du, 5, path=nat.MP_PATH_FFT)
+    monkeypatch.setattr(nat, "FFT_MAX_BATCH", 3)
+    parts = nat.encode(xd, du, 5, path=nat.MP_PATH_FFT)
+    assert all(torch.equal(a, b) for a, b in zip(whole, parts))
