@@ -54,13 +54,14 @@ extern "C" {
 #define MP_FLAG_FFT_SIMPLE 64 /* MP_PATH_FFT: plain radix-4 screen kernel instead of the register radix-16 one */
 #define MP_FLAG_FFT_PREFETCH 128 /* MP_PATH_FFT: register-prefetch the next pair's spectrum (more VGPRs) */
 #define MP_FLAG_FFT_WAVE 256 /* MP_PATH_FFT: one-wavefront-per-transform screen (M = 1024 / 2048 only)          */
-#define MP_FLAG_FFT_UNFUSED 512 /* MP_PATH_FFT: select-A / refine / select-B always as three kernels            */
-#define MP_FLAG_FFT_FUSED 1024  /* MP_PATH_FFT: ... always as one kernel (default: by cells per segment)        */
+#define MP_FLAG_FFT_UNFUSED 512 /* MP_PATH_FFT: select-A / refine / select-B as separate kernels plus the window kernel */
+#define MP_FLAG_FFT_FUSED 1024  /* MP_PATH_FFT: the whole-cell one-kernel select (default only for >= 65536 cells per
+                                   segment)                                                                        */
 #define MP_FLAG_OVERLAP 2048    /* sub-batches on forked internal streams (joined before returning); default for
-                                   MP_PATH_FFT from 32 segments up                                               */
-#define MP_FLAG_FFT_NO_QUARTER 8192 /* MP_PATH_FFT: small segments through scan+refine / select-B instead of the
-                                       one-kernel quarter-cell select                                           */
+                                   MP_PATH_FFT from 32 segments of < 65536 cells up                               */
 #define MP_FLAG_NO_OVERLAP 4096 /* never split the batch                                                          */
+#define MP_FLAG_FFT_NO_QUARTER 8192 /* MP_PATH_FFT: segments of <= 16384 cells through scan+refine / select-B instead
+                                       of the default one-kernel quarter-cell select                              */
 #define MP_FLAG_NO_PERSISTENT 8 /* one workgroup per 4 cells instead of machine-sized persistent grid */
 
 int mp_version(void);
