@@ -1,0 +1,49 @@
+#!/usr/bin/env python3
+"""Randomised parity sweep: the default schedule (and a few others) against the CPU oracle, bitwise, on shapes
+no fixed test uses -- odd atom counts, atoms longer than the segment's tail, batches that split unevenly
+into sub-batches, segments shorter than one transform.   fuzz_parity.py [n_cases] [seed]"""
+import os, sys
+import numpy as np, torch
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(REPO, "matching-pursuit_amd"))
+sys.path.insert(0, os.path.join(REPO, "oracle"))
+from mpcore import _native as nat
+from mpcore import synth
+import mp_oracle
+mp_oracle.build()
+n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 40
+rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 2024)
+paths = [("fft", nat.MP_PATH_FFT, 0), ("fft_one_stream", nat.MP_PATH_FFT, nat.MP_FLAG_NO_OVERLAP),
+         ("fft_scan_refine", nat.MP_PATH_FFT, nat.MP_FLAG_FFT_NO_QUARTER), ("fft_fused", nat.MP_PATH_FFT, nat.MP_FLAG_FFT_FUSED),
+         ("incremental", nat.MP_PATH_INCREMENTAL, 0)]
+bad = 0
+marked = 0
+for case in range(n_cases):
+    A = int(rng.integers(1, 90)); L = int(rng.choice([5, 16, 33, 64, 100, 128, 250, 300, 512, 700, 1100]))
+    N = int(rng.integers(max(L // 2, 40), 9000)); B = int(rng.choice([1, 2, 3, 7, 31, 32, 33, 45, 70])); K = int(rng.integers(1, 10))
+    d = synth.make_dictionary(A, L, seed=1000 + case)
+    x = synth.make_segments(B, N, d, n_events=min(3 * K, 12), seed=5000 + case) if N > L else \
+        rng.standard_normal((B, N)).astype(np.float32)
+    du = mp_oracle.unit_norm(d)
+    want = mp_oracle.encode(x, du, K)
+    gap = (want["top2"][..., 0] - want["top2"][..., 1]) / np.maximum(np.abs(want["top2"][..., 0]), 1e-30)
+    xd = torch.from_numpy(x).cuda(); dud = torch.from_numpy(du).cuda()
+    for name, path, flags in paths:
+        a, l, g, r = nat.encode(xd, dud, K, path=path, flags=flags)
+        a, l, g, r = a.cpu().numpy(), l.cpu().numpy(), g.cpu().numpy(), r.cpu().numpy()
+        nanrow = np.isnan(g).any(axis=1)
+        marked += int(nanrow.sum())
+        ok = True
+        for b in range(B):
+            if nanrow[b]:
+                continue  # screen overflow, marked in-band: allowed (the caller re-encodes)
+            if not (np.array_equal(a[b], want["atom"][b]) and np.array_equal(l[b], want["lag"][b]) and
+                    np.array_equal(g[b], want["gain"][b]) and np.array_equal(r[b], want["residual"][b])):
+                ok = False
+        if not ok:
+            bad += 1
+            print(f"MISMATCH case {case} {name}: A{A} L{L} N{N} B{B} K{K} min top-2 gap {gap.min():.2e}", flush=True)
+    if case % 10 == 9:
+        print(f"{case + 1} cases done, {bad} mismatches", flush=True)
+print("fuzz parity:", "OK" if bad == 0 else f"{bad} MISMATCHES", f"({marked} segment-runs marked as screen overflow)", flush=True)
+sys.exit(1 if bad else 0)
