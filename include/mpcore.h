@@ -180,6 +180,20 @@ int mp_scatter_rows_f32(const float *rows, const int64_t *batch, const int64_t *
 int mp_gather_sum_f32(const float *x, int64_t B, int64_t N, const int64_t *batch,
                       const int64_t *lag, int64_t n_events, int64_t L, double *out, void *stream);
 
+/*
+ * The atom-by-atom update loop of dictionary_learning_step (modules/matchingpursuit.py:391-415) in one
+ * launch.  Events are grouped by atom: group g (atom order[g], in first-selection order) owns events
+ * [offsets[g], offsets[g+1]) of ev_batch / ev_lag / ev_rows [E, L] (= d[atom] * value as materialised at
+ * encode time) / ev_norm [E] (= ||row||).  residual [B, N] starts as the ORIGINAL signal (:367) and is
+ * updated in place; dict_work [A, L] receives the new unit-norm atoms; sparse_zeroed is a [B, N] scratch that
+ * must be zero on entry and is zero again on return.  Single-device form; a multi-GPU run needs the per-atom
+ * all-reduce of mp_gather_sum_f32 between the two halves and keeps the step-by-step form.
+ */
+int mp_dictionary_update_f32(float *residual, float *sparse_zeroed, int64_t B, int64_t N, float *dict_work, int64_t A,
+                             int64_t L, const int64_t *order, const int64_t *offsets, int64_t n_groups,
+                             const int64_t *ev_batch, const int64_t *ev_lag, const float *ev_rows,
+                             const float *ev_norm, float eps, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

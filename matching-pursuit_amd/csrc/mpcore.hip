@@ -710,6 +710,93 @@ __global__ void gather_sum_kernel(const float *__restrict__ x, int64_t N, const 
 }
 
 // ------------------------------------------------------------------------------------------------
+// The atom-by-atom loop of dictionary_learning_step (modules/matchingpursuit.py:391-415) in ONE launch of ONE
+// workgroup: the loop is sequential by construction (every atom's update reads the residual the earlier
+// atoms left) and touches n_g * L samples per atom, so it is latency-, not bandwidth-bound -- as ~10 small
+// launches per atom it cost 54 ms at the headline shape, here the whole loop is a few ms.
+// Per used atom g (events [off[g], off[g+1]) in selection order), exactly what the reference's dense tensors do:
+//   sparse = scatter(rows of g);  residual += sparse            (:395-396; overlapping events sum first)
+//   acc[j] = sum_e residual[b_e, lag_e + j]  (fp64, event order; zero beyond N)          (:400-401)
+//   new    = acc / (||acc|| + 1e-8)           (unit_norm_kernel's arithmetic)                (:403-404)
+//   d[order[g]] = new;  sparse = scatter(new * ||row_e||);  residual -= sparse               (:406-415)
+// `sparse` is a zeroed [B, N] scratch; the kernel re-zeroes what it touched.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void dictionary_update_kernel(
+    float *__restrict__ residual, float *__restrict__ sparse, int64_t N, float *__restrict__ d_work, int64_t L,
+    const int64_t *__restrict__ order, const int64_t *__restrict__ off, int64_t n_groups,
+    const int64_t *__restrict__ ev_batch, const int64_t *__restrict__ ev_lag, const float *__restrict__ ev_rows,
+    const float *__restrict__ ev_norm, float eps) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float *nw = reinterpret_cast<float *>(smem);  // the new atom, L floats
+    __shared__ float s_den;
+    const int tid = threadIdx.x;
+    for (int64_t g = 0; g < n_groups; ++g) {
+        const int64_t e0 = off[g], e1 = off[g + 1];
+        // add the atom's events back: accumulate in `sparse` (event after event: they may overlap), then move
+        for (int64_t e = e0; e < e1; ++e) {
+            float *sp = sparse + ev_batch[e] * N + ev_lag[e];
+            const float *row = ev_rows + e * L;
+            const int64_t len = N - ev_lag[e] < L ? N - ev_lag[e] : L;
+            for (int64_t s = tid; s < len; s += 1024) sp[s] = __fadd_rn(sp[s], row[s]);
+            __syncthreads();
+        }
+        for (int64_t e = e0; e < e1; ++e) {
+            const int64_t base = ev_batch[e] * N + ev_lag[e];
+            const int64_t len = N - ev_lag[e] < L ? N - ev_lag[e] : L;
+            for (int64_t s = tid; s < len; s += 1024) {
+                residual[base + s] = __fadd_rn(residual[base + s], sparse[base + s]);
+                sparse[base + s] = 0.0f;  // an overlapping later event then adds an exact zero
+            }
+            __syncthreads();
+        }
+        // sum of the residual windows, then the unit-norm atom
+        for (int64_t j = tid; j < L; j += 1024) {
+            double acc = 0.0;
+            for (int64_t e = e0; e < e1; ++e) {
+                const int64_t t = ev_lag[e] + j;
+                if (t < N) acc += (double)residual[ev_batch[e] * N + t];
+            }
+            nw[j] = (float)acc;
+        }
+        __syncthreads();
+        if (tid == 0) {
+            double ss = 0.0;
+            for (int64_t j = 0; j < L; ++j) {
+                const double x = (double)nw[j];
+                ss += x * x;
+            }
+            s_den = __fadd_rn(__fsqrt_rn((float)ss), eps);
+        }
+        __syncthreads();
+        const float den = s_den;
+        float *drow = d_work + order[g] * L;
+        for (int64_t j = tid; j < L; j += 1024) {
+            const float v = __fdiv_rn(nw[j], den);
+            nw[j] = v;
+            drow[j] = v;
+        }
+        __syncthreads();
+        // take the new atom out again with the magnitudes the old instances had
+        for (int64_t e = e0; e < e1; ++e) {
+            float *sp = sparse + ev_batch[e] * N + ev_lag[e];
+            const float nrm = ev_norm[e];
+            const int64_t len = N - ev_lag[e] < L ? N - ev_lag[e] : L;
+            for (int64_t s = tid; s < len; s += 1024) sp[s] = __fadd_rn(sp[s], __fmul_rn(nw[s], nrm));
+            __syncthreads();
+        }
+        for (int64_t e = e0; e < e1; ++e) {
+            const int64_t base = ev_batch[e] * N + ev_lag[e];
+            const int64_t len = N - ev_lag[e] < L ? N - ev_lag[e] : L;
+            for (int64_t s = tid; s < len; s += 1024) {
+                residual[base + s] = __fsub_rn(residual[base + s], sparse[base + s]);
+                sparse[base + s] = 0.0f;
+            }
+            __syncthreads();
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // Workspace carving (all offsets multiples of 256 bytes)
 // ------------------------------------------------------------------------------------------------
 #include "mpfft.inc"
@@ -1452,6 +1539,25 @@ int mp_gather_sum_f32(const float *x, int64_t B, int64_t N, const int64_t *batch
         return fail(MP_ERR_ARG, "mp_gather_sum_f32: bad arguments%s");
     hipLaunchKernelGGL(gather_sum_kernel, dim3((unsigned)((L + 255) / 256)), dim3(256), 0,
                        static_cast<hipStream_t>(stream), x, N, batch, lag, n_events, L, out);
+    HIP_TRY(hipGetLastError());
+    return MP_OK;
+}
+
+int mp_dictionary_update_f32(float *residual, float *sparse_zeroed, int64_t B, int64_t N, float *dict_work, int64_t A,
+                             int64_t L, const int64_t *order, const int64_t *offsets, int64_t n_groups,
+                             const int64_t *ev_batch, const int64_t *ev_lag, const float *ev_rows,
+                             const float *ev_norm, float eps, void *stream) {
+    if (n_groups == 0) return MP_OK;
+    if (!residual || !sparse_zeroed || !dict_work || !order || !offsets || !ev_batch || !ev_lag || !ev_rows ||
+        !ev_norm || B <= 0 || N <= 0 || A <= 0 || L <= 0 || n_groups < 0)
+        return fail(MP_ERR_ARG, "mp_dictionary_update_f32: bad arguments%s");
+    const size_t lds = (size_t)L * sizeof(float);
+    if (lds > 150 * 1024) return fail(MP_ERR_UNSUPPORTED, "mp_dictionary_update_f32: atom too long for LDS%s");
+    if (lds > 64 * 1024)
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(dictionary_update_kernel),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(dictionary_update_kernel, dim3(1), dim3(1024), lds, static_cast<hipStream_t>(stream), residual,
+                       sparse_zeroed, N, dict_work, L, order, offsets, n_groups, ev_batch, ev_lag, ev_rows, ev_norm, eps);
     HIP_TRY(hipGetLastError());
     return MP_OK;
 }

@@ -38,6 +38,7 @@ EXPORTS = (
     "mp_version", "mp_last_error", "mp_workspace_bytes", "mp_unit_norm_f32", "mp_encode_f32",
     "mp_feature_map_f32", "mp_scatter_f32", "mp_scatter_rows_f32", "mp_gather_sum_f32",
     "mp_profile_enable", "mp_profile_read", "mp_fft_c2c_f32", "mp_encode_conv_f32", "mp_tune",
+    "mp_dictionary_update_f32",
 )
 
 _lib = None
@@ -69,6 +70,8 @@ def lib():
         L.mp_scatter_f32.argtypes = [vp, vp, vp, vp, i64, vp, i64, i64, vp, i64, i64, vp]
         L.mp_scatter_rows_f32.argtypes = [vp, vp, vp, i64, i64, vp, i64, i64, vp]
         L.mp_gather_sum_f32.argtypes = [vp, i64, i64, vp, vp, i64, i64, vp, vp]
+        L.mp_dictionary_update_f32.argtypes = [vp, vp, i64, i64, vp, i64, i64, vp, vp, i64, vp, vp, vp, vp,
+                                               ctypes.c_float, vp]
         L.mp_fft_c2c_f32.argtypes = [vp, vp, ctypes.c_int, i64, ctypes.c_int, vp, vp]
         for name in EXPORTS:
             getattr(L, name)
@@ -292,3 +295,23 @@ def gather_sum(x, batch, lag, L):
                                      _ptr(out), _stream(x))
     _check(rc, "mp_gather_sum_f32")
     return out
+
+
+def dictionary_update(residual, d_work, order, offsets, ev_batch, ev_lag, ev_rows, ev_norm, eps=1e-8):
+    """mp_dictionary_update_f32: the atom-by-atom loop of dictionary_learning_step in one launch.
+    residual [B, N] and d_work [A, L] are updated in place."""
+    _require_cuda(residual, d_work)
+    assert residual.dtype == torch.float32 and residual.is_contiguous() and d_work.is_contiguous()
+    dev = residual.device
+    B, N = residual.shape
+    A, L = d_work.shape
+    order, offsets = _i64(order, dev), _i64(offsets, dev)
+    ev_batch, ev_lag = _i64(ev_batch, dev), _i64(ev_lag, dev)
+    ev_rows, ev_norm = _f32(ev_rows), _f32(ev_norm)
+    sparse = torch.zeros_like(residual)
+    with torch.cuda.device(dev):
+        rc = lib().mp_dictionary_update_f32(_ptr(residual), _ptr(sparse), B, N, _ptr(d_work), A, L, _ptr(order),
+                                            _ptr(offsets), order.numel(), _ptr(ev_batch), _ptr(ev_lag), _ptr(ev_rows),
+                                            _ptr(ev_norm), ctypes.c_float(eps), _stream(residual))
+    _check(rc, "mp_dictionary_update_f32")
+    sparse.record_stream(torch.cuda.current_stream(dev))

@@ -418,6 +418,15 @@ def dictionary_learning_step(
     ev_rows = rows.reshape(-1, atom_size)[perm_d]
     ev_norm = anorm.reshape(-1)[perm_d]
 
+    if not _dist.is_distributed(process_group):
+        # single device: the whole atom-by-atom loop in one launch (mp_dictionary_update_f32)
+        counts_t = torch.as_tensor(counts, dtype=torch.int64)
+        offsets = torch.zeros(len(order) + 1, dtype=torch.int64)
+        offsets[1:] = torch.cumsum(counts_t, 0)
+        _native.dictionary_update(residual, d_work, torch.as_tensor(order, dtype=torch.int64), offsets, ev_batch,
+                                  ev_lag, ev_rows.contiguous(), ev_norm.contiguous())
+        return _native.unit_norm(d_work).to(out_dev)  # :417-419
+
     sparse = torch.empty_like(residual)
     start = 0
     for oi, index in enumerate(order):
