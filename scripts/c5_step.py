@@ -1,0 +1,29 @@
+#!/usr/bin/env python3
+"""BASELINE configs[4] (the gradient-trained dictionary of mp.py): time per train step on one GPU.
+512 x 512 atoms, 8 x 32768-sample segments, 32 iterations, STFT(2048, 256) iterative loss."""
+import os, sys, time
+import numpy as np, torch
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(REPO, "matching-pursuit_amd"))
+from mpcore import synth
+from mpcore.model import MatchingPursuit, train_step
+A, L, N, B, K = 512, 512, 32768, 8, 32
+dev = "cuda:0"
+torch.manual_seed(0)
+model = MatchingPursuit(A, L, N, K).to(dev)
+with torch.no_grad():
+    model.atoms.copy_(torch.from_numpy(synth.make_dictionary(A, L, seed=5000))[None].to(dev) * 0.05)
+opt = torch.optim.Adam(model.parameters(), lr=1e-3)
+x = torch.from_numpy(synth.make_segments(B, N, synth.make_dictionary(A, L, seed=5000), n_events=96, seed=5001)).to(dev)[:, None, :]
+win = torch.hann_window(2048, device=dev)
+def transform(t):
+    b = t.shape[0]
+    s = torch.stft(t.reshape(-1, t.shape[-1]), 2048, 256, window=win, return_complex=True, center=True)
+    return torch.abs(s).reshape(b, -1, s.shape[-2] * s.shape[-1])
+losses, ts = [], []
+for it in range(8):
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    losses.append(train_step(model, opt, x, transform))
+    torch.cuda.synchronize(); ts.append((time.perf_counter() - t0) * 1e3)
+print("loss", [round(l, 3) for l in losses])
+print(f"train step: median {np.median(ts[2:]):.1f} ms  ({B * K / np.median(ts[2:]) * 1e3:.0f} segment-iterations/s incl. backward and the STFT loss)")
