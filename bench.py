@@ -10,11 +10,14 @@ rank per GPU) every rank encodes its own 64 segments (configs[2] at N = 8: 512 s
 collective on the data path, weak scaling; rank 0 prints ONE JSON line.
 
 value = segment-iterations/s over all ranks, inputs resident in HBM, timed between
-barrier+synchronize pairs, max over ranks, on the library's default schedule (MP_PATH_FFT: FFT
-screen + exact refinement; events bit-identical to the direct paths, re-checked every run).
-`roofline` is for that schedule's dominant kernel from HIP events recorded inside the timed region on
-the launch stream; `variants` carries the two direct-correlation (MFMA) schedules with their own
-rooflines; `cpu_baseline` is the CPU oracle timed on this host (rank 0, N = 1 only).
+barrier+synchronize pairs, max over ranks, on the library's default kernels (MP_PATH_FFT: FFT
+screen + exact refinement; events bit-identical to the direct paths, re-checked every run) with the
+batch kept on ONE stream (MP_FLAG_NO_OVERLAP), so that the event-timed kernel durations are not
+stretched by a second sub-batch; `variants` carries the library's own default (two sub-batches on
+forked streams, a few percent faster) and the two direct-correlation (MFMA) schedules with their own
+rooflines.  `roofline` is for the dominant kernel from HIP events recorded inside the timed region on
+the launch stream (sampled: every 16th iteration, see launch_times); `cpu_baseline` is the CPU oracle
+timed on this host (rank 0, N = 1 only).
 """
 import argparse
 import json
