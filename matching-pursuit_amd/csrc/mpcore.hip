@@ -1111,7 +1111,7 @@ int fft_iteration(const Geom &g, const Workspace &w, const float *du, int K, int
             MP_FFT_DISPATCH(f.logM, {
                 hipLaunchKernelGGL(fft_window_kernel<LG>, dim3(nw, (unsigned)g.B), dim3(256), lds, st, w.res, g.Ns,
                                    dirty, w.tw, w.xspec, w.wnorm, f.V, f.NW,
-                                   rule.square ? w.dscale : (const float *)nullptr);
+                                   (const float *)w.dscale);
             })
         }
         g_prof.end(st);
@@ -1169,7 +1169,7 @@ int fft_iteration(const Geom &g, const Workspace &w, const float *du, int K, int
                 hipLaunchKernelGGL(fft_select_quarter_kernel<LQ>, dim3((unsigned)g.B), dim3(1024), lds_q, st, w.keys,
                                    w.ceps, w.subk, n_cells, w.res, du, w.dirty, w.overflow, out_atom, out_lag, out_gain,
                                    g.N, g.A, g.L, g.Ns, g.NBLK, g.NAT, K, k, rule.du_sub, rule.shift, rule.square, w.tw,
-                                   w.xspec, w.wnorm, f.NW, rule.square ? w.dscale : (const float *)nullptr);
+                                   w.xspec, w.wnorm, f.NW, (const float *)w.dscale);
             })
         } else if (fused) {
             const size_t lds_chain = (size_t)(round_up(g.L, 64) + 128) * sizeof(float);
@@ -1180,7 +1180,7 @@ int fft_iteration(const Geom &g, const Workspace &w, const float *du, int K, int
                 hipLaunchKernelGGL(fft_select_fused_kernel<LT>, dim3((unsigned)g.B), dim3(1024), lds_f, st, w.keys,
                                    w.ceps, n_cells, w.res, du, w.dirty, w.overflow, out_atom, out_lag, out_gain,
                                    g.N, g.A, g.L, g.Ns, g.NBLK, g.NAT, K, k, rule.du_sub, rule.shift, rule.square,
-                                   w.tw, w.xspec, w.wnorm, f.NW, rule.square ? w.dscale : (const float *)nullptr);
+                                   w.tw, w.xspec, w.wnorm, f.NW, (const float *)w.dscale);
             })
         } else {
             // select-A merged into the refinement launch when select-B is the kernel that clears the slots
@@ -1214,7 +1214,7 @@ int fft_iteration(const Geom &g, const Workspace &w, const float *du, int K, int
                     hipLaunchKernelGGL(fft_select_b_kernel<LB>, dim3((unsigned)g.B), dim3(256), lds_b, st, w.ekeys,
                                        w.res, rule.du_sub, w.dirty, out_atom, out_lag, out_gain, g.N, g.L, g.Ns, g.NBLK,
                                        g.NAT, K, k, w.cont, w.ncont, w.keys, w.ceps, rule.shift, rule.square, w.tw,
-                                       w.xspec, w.wnorm, f.NW, rule.square ? w.dscale : (const float *)nullptr);
+                                       w.xspec, w.wnorm, f.NW, (const float *)w.dscale);
                 })
             } else {
                 hipLaunchKernelGGL(select_subtract_kernel, dim3((unsigned)g.B), dim3(256), 0, st, w.ekeys,
@@ -1363,8 +1363,11 @@ static int encode_impl(const float *signal, int64_t B, int64_t N, const float *d
     rc = stage_inputs(g, w, path, signal, dict_unit, rule.lead, st);
     if (rc) return rc;
     if (path == MP_PATH_FFT && (rc = fft_setup(g, w, dict_unit, flags, st))) return rc;
-    if (path == MP_PATH_FFT && conv_model) {
-        hipLaunchKernelGGL(max_row_norm_kernel, dim3(1), dim3(256), 0, st, dict_in, A, L, w.dscale);
+    if (path == MP_PATH_FFT) {
+        // the screen's bound |fm| <= ||window|| * max_a ||d_a||: 1 for the unit-norm dictionary this entry point
+        // is documented for, but measured rather than trusted (and the convolution model's atoms are raw)
+        HIP_TRY(hipMemsetAsync(w.dscale, 0, sizeof(float), st));
+        hipLaunchKernelGGL(max_row_norm_kernel, dim3((unsigned)((A + 3) / 4)), dim3(256), 0, st, dict_in, A, L, w.dscale);
         HIP_TRY(hipGetLastError());
     }
 

@@ -328,3 +328,18 @@ def test_random_shapes_default_schedule_is_bitwise(oracle):
         assert keep.mean() > 0.9, (A, L, N, B, K)
         for name, got in (("atom", atom), ("lag", lag), ("gain", gain), ("residual", res)):
             assert np.array_equal(got[keep], want[name][keep]), (name, A, L, N, B, K)
+
+
+def test_fft_screen_bound_follows_the_dictionary_norm(oracle):
+    """mp_encode_f32 is documented for a unit-norm dictionary, but the screen's error bound uses the measured
+    largest atom norm: atoms scaled by up to 3 still give the oracle's events bit for bit."""
+    rng = np.random.default_rng(9)
+    du = oracle.unit_norm(synth.make_dictionary(40, 96, seed=9))
+    x = synth.make_segments(5, 3000, du, n_events=12, seed=10)
+    scaled = (du * rng.uniform(0.5, 3.0, size=(40, 1)).astype(np.float32)).astype(np.float32)
+    want = oracle.encode(x, scaled, 6)
+    for flags in (0, nat.MP_FLAG_FFT_NO_QUARTER, nat.MP_FLAG_FFT_FUSED):
+        atom, lag, gain, res = _gpu_encode(x, scaled, 6, nat.MP_PATH_FFT, flags)
+        assert not np.isnan(gain).any()
+        assert np.array_equal(atom, want["atom"]) and np.array_equal(lag, want["lag"])
+        assert np.array_equal(gain, want["gain"]) and np.array_equal(res, want["residual"])
