@@ -52,8 +52,7 @@ extern "C" {
 #define MP_FLAG_NO_STAGGER 16 /* do not delay odd wave slots by half a cell on incremental launches */
 #define MP_FLAG_REFINE_MFMA 32 /* MP_PATH_FFT: refine contender cells on the MFMA cell code instead of VALU chains */
 #define MP_FLAG_FFT_SIMPLE 64 /* MP_PATH_FFT: plain radix-4 screen kernel instead of the register radix-16 one */
-#define MP_FLAG_FFT_PREFETCH 128 /* MP_PATH_FFT: register-prefetch the next pair's spectrum (more VGPRs) */
-#define MP_FLAG_FFT_WAVE 256 /* MP_PATH_FFT: one-wavefront-per-transform screen (M = 1024 / 2048 only)          */
+/* (128 and 256 were two dominated screen variants, removed: do not reuse) */
 #define MP_FLAG_FFT_UNFUSED 512 /* MP_PATH_FFT: select-A / refine / select-B as separate kernels plus the window kernel */
 #define MP_FLAG_FFT_FUSED 1024  /* MP_PATH_FFT: the whole-cell one-kernel select (default only for >= 65536 cells per
                                    segment)                                                                        */

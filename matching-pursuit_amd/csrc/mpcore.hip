@@ -1100,7 +1100,7 @@ int fft_iteration(const Geom &g, const Workspace &w, const float *du, int K, int
     // per-quarter maxima, hence its register transform at pps = 4)
     const bool quarter = w.subk && f.logM >= 10 &&
                          !(flags & (MP_FLAG_REFINE_MFMA | MP_FLAG_FFT_UNFUSED | MP_FLAG_FFT_FUSED | MP_FLAG_FFT_SIMPLE |
-                                    MP_FLAG_FFT_WAVE | MP_FLAG_FFT_NO_QUARTER));
+                                    MP_FLAG_FFT_NO_QUARTER));
     const bool b_tail = !fused && !quarter && !(flags & MP_FLAG_FFT_SIMPLE) && f.logM >= 10 && f.logM <= 12;
     const bool fused_tail = (fused && f.logM >= 10) || b_tail || quarter;
     {
@@ -1117,17 +1117,7 @@ int fft_iteration(const Geom &g, const Workspace &w, const float *du, int K, int
         g_prof.end(st);
         g_prof.begin(k == 0 ? PROF_CORR_FULL : PROF_CORR_INC, st);
         MP_FFT_DISPATCH(f.logM, {
-            if ((LG == 10 || LG == 11) && (flags & MP_FLAG_FFT_WAVE) && !(flags & MP_FLAG_FFT_SIMPLE)) {
-                constexpr int LW = (LG == 10 || LG == 11) ? LG : 10;  // (dead branch for other LG)
-                int pps = 16;
-                const int64_t tasks = (int64_t)nw * g.NAT * g.B;
-                while (pps > 1 && tasks * (16 / pps) < 32 * (int64_t)num_cus()) pps >>= 1;
-                if (screen_pps_override > 0 && 16 % screen_pps_override == 0) pps = screen_pps_override;
-                const size_t lds_s = ((size_t)(1 << LW) + (1 << LW) / 64 + 64) * sizeof(cpx);
-                hipLaunchKernelGGL(fft_screen_wave_kernel<LW>, dim3(nw * (16 / pps), g.NAT, (unsigned)g.B), dim3(64),
-                                   lds_s, st, w.xspec, w.pspec, w.tw, dirty, w.wnorm, w.keys, w.ceps, g.N, g.A,
-                                   g.NBLK, g.NAT, f.V, f.NW, FFT_TAU, pps);
-            } else if (LG >= 10 && !(flags & MP_FLAG_FFT_SIMPLE)) {
+            if (LG >= 10 && !(flags & MP_FLAG_FFT_SIMPLE)) {
                 constexpr int LS = LG >= 10 ? LG : 10;  // (the branch is dead for smaller LG)
                 using C = ScreenCfg<LS>;
                 // pairs per slot: fewest workgroups that still oversubscribe the machine ~8x
@@ -1142,15 +1132,9 @@ int fft_iteration(const Geom &g, const Workspace &w, const float *du, int K, int
                 const bool seg_fast = (size_t)g.NAT * f.NPT * f.M * sizeof(cpx) > (size_t)16 << 20;
                 const unsigned gwp = nw * (16 / (C::SLOTS * pps));
                 const dim3 grid = seg_fast ? dim3((unsigned)g.B, gwp, g.NAT) : dim3(gwp, g.NAT, (unsigned)g.B);
-                if (flags & MP_FLAG_FFT_PREFETCH) {
-                    if ((rc = fft_lds_attr(fft_screen_kernel<LS, true>, lds_s))) return rc;
-                    hipLaunchKernelGGL((fft_screen_kernel<LS, true>), grid, dim3(C::WG), lds_s, st, w.xspec, w.pspec, w.tw,
-                                       dirty, w.wnorm, w.keys, w.ceps, g.N, g.A, g.NBLK, g.NAT, f.V, f.NW, FFT_TAU, pps, (int)seg_fast, subk);
-                } else {
-                    if ((rc = fft_lds_attr(fft_screen_kernel<LS, false>, lds_s))) return rc;
-                    hipLaunchKernelGGL((fft_screen_kernel<LS, false>), grid, dim3(C::WG), lds_s, st, w.xspec, w.pspec, w.tw,
-                                       dirty, w.wnorm, w.keys, w.ceps, g.N, g.A, g.NBLK, g.NAT, f.V, f.NW, FFT_TAU, pps, (int)seg_fast, subk);
-                }
+                if ((rc = fft_lds_attr(fft_screen_kernel<LS>, lds_s))) return rc;
+                hipLaunchKernelGGL(fft_screen_kernel<LS>, grid, dim3(C::WG), lds_s, st, w.xspec, w.pspec, w.tw, dirty,
+                                   w.wnorm, w.keys, w.ceps, g.N, g.A, g.NBLK, g.NAT, f.V, f.NW, FFT_TAU, pps, (int)seg_fast, subk);
             } else {
                 hipLaunchKernelGGL(fft_correlate_kernel<LG>, dim3(nw, g.NAT, (unsigned)g.B), dim3(256), lds, st,
                                    w.xspec, w.pspec, w.tw, dirty, w.wnorm, w.keys, w.ceps, g.N, g.A, g.NBLK,

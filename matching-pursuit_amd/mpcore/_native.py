@@ -23,13 +23,11 @@ MP_FLAG_NO_PERSISTENT = 8
 MP_FLAG_NO_STAGGER = 16
 MP_FLAG_REFINE_MFMA = 32
 MP_FLAG_FFT_SIMPLE = 64
-MP_FLAG_FFT_PREFETCH = 128
 MP_TUNE_TAU = 1
 MP_TUNE_SCREEN_PPS = 2
 MP_TUNE_GROUPS = 3
 MP_FLAG_NO_OVERLAP = 4096
 MP_FLAG_FFT_NO_QUARTER = 8192
-MP_FLAG_FFT_WAVE = 256
 MP_FLAG_FFT_UNFUSED = 512
 MP_FLAG_FFT_FUSED = 1024
 MP_FLAG_OVERLAP = 2048

@@ -34,9 +34,7 @@ PATHS = [
     ("fft_fused", nat.MP_PATH_FFT, nat.MP_FLAG_FFT_FUSED),
     ("fft_scan_refine", nat.MP_PATH_FFT, nat.MP_FLAG_FFT_NO_QUARTER),
     ("fft_one_stream", nat.MP_PATH_FFT, nat.MP_FLAG_NO_OVERLAP),
-    ("fft_wave", nat.MP_PATH_FFT, nat.MP_FLAG_FFT_WAVE),
     ("fft_simple", nat.MP_PATH_FFT, nat.MP_FLAG_FFT_SIMPLE),
-    ("fft_prefetch", nat.MP_PATH_FFT, nat.MP_FLAG_FFT_PREFETCH),
     ("incremental_nonpersistent", nat.MP_PATH_INCREMENTAL, nat.MP_FLAG_NO_PERSISTENT),
     ("direct_nonpersistent_nodma", nat.MP_PATH_DIRECT, nat.MP_FLAG_NO_PERSISTENT | nat.MP_FLAG_NO_DMA),
     ("incremental_ta64_nodma", nat.MP_PATH_INCREMENTAL, nat.MP_FLAG_TA64 | nat.MP_FLAG_NO_DMA),
