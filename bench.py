@@ -171,6 +171,14 @@ def roofline_fft(prof, n_segments, steps):
                 "VALU / LDS limited, see DESIGN.md",
         "survey_8d_equivalent_gbs": round(survey_bytes * steps / sec / 1e9, 1),
     })
+    # the resource that actually binds the kernel: packed-fp32 VALU issue.  ~410 VALU instructions per
+    # 16-point thread-transform (353 of them v_pk_{add,mul,fma}_f32; counted in the ISA), M / 16 threads per
+    # transform, 4 issue cycles per wave64 instruction, 1024 SIMDs at the 2.4 GHz peak clock
+    transforms = n_segments * (A // 2) * (-(-N // V) + K_ITERS - 1) * steps
+    valu_floor_s = transforms * (M // 16 // 64) * 410 * 4 / (1024 * 2.4e9)
+    out["valu_issue"] = {"transforms": transforms, "floor_ms_per_launch": round(valu_floor_s * 1e3 / per_kind["launches"], 5),
+                         "frac_of_measured": round(valu_floor_s / sec, 4),
+                         "note": "time the VALU instructions alone need at 2.4 GHz / measured kernel time"}
     return out
 
 
