@@ -60,7 +60,8 @@ extern "C" {
                                    MP_PATH_FFT from 32 segments of < 65536 cells up                               */
 #define MP_FLAG_NO_OVERLAP 4096 /* never split the batch                                                          */
 #define MP_FLAG_FFT_NO_QUARTER 8192 /* MP_PATH_FFT: segments of <= 16384 cells through scan+refine / select-B instead
-                                       of the default one-kernel quarter-cell select                              */
+                                       of the one-kernel quarter-cell select (default when the batch is split)    */
+#define MP_FLAG_FFT_QUARTER 16384   /* MP_PATH_FFT: the quarter-cell select also when the batch stays on one stream */
 #define MP_FLAG_NO_PERSISTENT 8 /* one workgroup per 4 cells instead of machine-sized persistent grid */
 
 int mp_version(void);

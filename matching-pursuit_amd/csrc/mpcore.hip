@@ -84,6 +84,7 @@ constexpr int LAGS_PER_WAVE = 64;   // one cell = TA atoms x 64 lags, owned by o
 constexpr int WAVES = 4;            // wavefronts per workgroup
 constexpr int KC_MAX = 512;         // atom samples staged in LDS per chunk
 constexpr int MAXCONT = 32;         // FFT path: inexact contender cells per segment per iteration
+constexpr int MP_FLAG_INTERNAL_ONE_STREAM = 1 << 30;  // set by encode_impl: the batch is not split
 constexpr int64_t QUARTER_MAX_CELLS = 16384;  // FFT path: segments this small use the quarter-cell select kernel
 
 __host__ __device__ inline int64_t round_up(int64_t x, int64_t m) { return (x + m - 1) / m * m; }
@@ -1098,9 +1099,14 @@ int fft_iteration(const Geom &g, const Workspace &w, const float *du, int K, int
     // for this size (the stand-alone window kernel then runs before the first step only)
     // ... or, for small segments, ONE kernel that refines only a quarter of a contender cell (needs the screen's
     // per-quarter maxima, hence its register transform at pps = 4)
+    // Measured at the headline shape: with the batch on one stream the two-launch form (screen at pps = 8) is
+    // 1-2 % ahead, with two sub-batches on forked streams the quarter kernel is 3 % ahead -- so each gets the
+    // schedule it is better under (MP_FLAG_FFT_QUARTER / MP_FLAG_FFT_NO_QUARTER force either).
+    const bool two_launch_ok = f.logM <= 12 && n_cells <= 16384;
     const bool quarter = w.subk && f.logM >= 10 &&
                          !(flags & (MP_FLAG_REFINE_MFMA | MP_FLAG_FFT_UNFUSED | MP_FLAG_FFT_FUSED | MP_FLAG_FFT_SIMPLE |
-                                    MP_FLAG_FFT_NO_QUARTER));
+                                    MP_FLAG_FFT_NO_QUARTER)) &&
+                         ((flags & MP_FLAG_FFT_QUARTER) || !((flags & MP_FLAG_INTERNAL_ONE_STREAM) && two_launch_ok));
     const bool b_tail = !fused && !quarter && !(flags & MP_FLAG_FFT_SIMPLE) && f.logM >= 10 && f.logM <= 12;
     const bool fused_tail = (fused && f.logM >= 10) || b_tail || quarter;
     {
@@ -1322,6 +1328,7 @@ static int encode_impl(const float *signal, int64_t B, int64_t N, const float *d
                        void *stream, bool conv_model) {
     int rc = check_shape(B, N, A, L, K);
     if (rc) return rc;
+    flags &= ~MP_FLAG_INTERNAL_ONE_STREAM;  // ours to set
     if (path != MP_PATH_DIRECT && path != MP_PATH_INCREMENTAL && path != MP_PATH_NAIVE && path != MP_PATH_FFT)
         return fail(MP_ERR_ARG, "unknown path%s");
     if (path == MP_PATH_NAIVE && (B > 65535 || A > 65535))
@@ -1388,7 +1395,9 @@ static int encode_impl(const float *signal, int64_t B, int64_t N, const float *d
             int64_t *oa = out_atom + b0 * K, *ol = out_lag + b0 * K;
             float *og = out_gain + b0 * K;
             if (path == MP_PATH_FFT) {
-                if ((rc = fft_iteration(gq, wq, dict_unit, K, k, flags, oa, ol, og, rule, sq))) return rc;
+                if ((rc = fft_iteration(gq, wq, dict_unit, K, k, flags | (n_groups == 1 ? MP_FLAG_INTERNAL_ONE_STREAM : 0),
+                                        oa, ol, og, rule, sq)))
+                    return rc;
                 continue;
             }
             const bool full = (k == 0) || !incremental;

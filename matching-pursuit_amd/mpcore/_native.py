@@ -28,6 +28,7 @@ MP_TUNE_SCREEN_PPS = 2
 MP_TUNE_GROUPS = 3
 MP_FLAG_NO_OVERLAP = 4096
 MP_FLAG_FFT_NO_QUARTER = 8192
+MP_FLAG_FFT_QUARTER = 16384
 MP_FLAG_FFT_UNFUSED = 512
 MP_FLAG_FFT_FUSED = 1024
 MP_FLAG_OVERLAP = 2048

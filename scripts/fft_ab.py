@@ -12,7 +12,7 @@ A, L, N, B, K = {"c2": (512, 512, 32768, 64, 64), "c4": (4096, 2048, 131072, 16,
 # (name, path, flags, tau, screen pairs-per-slot override, sub-batches)
 NO = nat.MP_FLAG_NO_OVERLAP
 variants = [("fft", 1, 0, 2e-5, 0, 2), ("fft_groups3", 1, 0, 2e-5, 0, 3), ("fft_groups4", 1, 0, 2e-5, 0, 4),
-            ("fft_one_stream", 1, NO, 2e-5, 0, 2), ("fft_scan_refine_one_stream", 1, NO | nat.MP_FLAG_FFT_NO_QUARTER, 2e-5, 0, 2),
+            ("fft_one_stream", 1, NO, 2e-5, 0, 2), ("fft_quarter_one_stream", 1, NO | nat.MP_FLAG_FFT_QUARTER, 2e-5, 0, 2), ("fft_scan_refine_one_stream", 1, NO | nat.MP_FLAG_FFT_NO_QUARTER, 2e-5, 0, 2),
             ("fft_pps4", 1, 0, 2e-5, 4, 2), ("fft_pps8", 1, 0, 2e-5, 8, 2),
             ("fft_unfused", 1, nat.MP_FLAG_FFT_UNFUSED, 2e-5, 0, 2), ("fft_fused", 1, nat.MP_FLAG_FFT_FUSED, 2e-5, 0, 2),
             ("fft_fused_one_stream", 1, nat.MP_FLAG_FFT_FUSED | NO, 2e-5, 0, 2),

@@ -33,6 +33,8 @@ PATHS = [
     ("fft_unfused", nat.MP_PATH_FFT, nat.MP_FLAG_FFT_UNFUSED),
     ("fft_fused", nat.MP_PATH_FFT, nat.MP_FLAG_FFT_FUSED),
     ("fft_scan_refine", nat.MP_PATH_FFT, nat.MP_FLAG_FFT_NO_QUARTER),
+    ("fft_quarter", nat.MP_PATH_FFT, nat.MP_FLAG_FFT_QUARTER),
+    ("fft_quarter_one_stream", nat.MP_PATH_FFT, nat.MP_FLAG_FFT_QUARTER | nat.MP_FLAG_NO_OVERLAP),
     ("fft_one_stream", nat.MP_PATH_FFT, nat.MP_FLAG_NO_OVERLAP),
     ("fft_simple", nat.MP_PATH_FFT, nat.MP_FLAG_FFT_SIMPLE),
     ("incremental_nonpersistent", nat.MP_PATH_INCREMENTAL, nat.MP_FLAG_NO_PERSISTENT),
