@@ -86,6 +86,7 @@ constexpr int KC_MAX = 512;         // atom samples staged in LDS per chunk
 constexpr int MAXCONT = 32;         // FFT path: inexact contender cells per segment per iteration
 constexpr int MP_FLAG_INTERNAL_ONE_STREAM = 1 << 30;  // set by encode_impl: the batch is not split
 constexpr int64_t QUARTER_MAX_CELLS = 16384;  // FFT path: segments this small use the quarter-cell select kernel
+constexpr int64_t FUSED_MIN_CELLS = 65536;    // FFT path: from here the whole-cell one-kernel select, with block summaries
 
 __host__ __device__ inline int64_t round_up(int64_t x, int64_t m) { return (x + m - 1) / m * m; }
 
@@ -814,6 +815,7 @@ struct Workspace {
     int *cont, *ncont, *overflow;
     float *dscale;  // max atom norm (convolution model: atoms are not unit norm)
     float *subk;    // per-quarter-cell screen maxima [B][cells][SUBCELLS]; only for <= QUARTER_MAX_CELLS
+    unsigned *bsum; // per-block (upper, lower) bound summaries [B][NBLK][2]; used for >= FUSED_MIN_CELLS
     u64 *ekeys;
     size_t bytes;
 };
@@ -839,6 +841,7 @@ Workspace carve(const Geom &g, int path, char *base) {
     w.ekeys = nullptr;
     w.dscale = nullptr;
     w.subk = nullptr;
+    w.bsum = nullptr;
     if (path == MP_PATH_FFT) {
         FftGeom f;
         if (make_fft_geom(g, &f)) {
@@ -852,6 +855,7 @@ Workspace carve(const Geom &g, int path, char *base) {
             size_t o_ov = take((size_t)g.B * sizeof(int));
             size_t o_ek = take((size_t)g.B * (MAXCONT + 1) * sizeof(u64));
             size_t o_ds = take(256);
+            size_t o_bs = take((size_t)g.B * g.NBLK * 2 * sizeof(unsigned));
             const bool quarters = (int64_t)g.NBLK * g.NAT <= QUARTER_MAX_CELLS;
             size_t o_sk = take(quarters ? (size_t)g.B * g.NBLK * g.NAT * SUBCELLS * sizeof(float) : 0);
             w.tw = reinterpret_cast<cpx *>(base + o_tw);
@@ -864,6 +868,7 @@ Workspace carve(const Geom &g, int path, char *base) {
             w.overflow = reinterpret_cast<int *>(base + o_ov);
             w.ekeys = reinterpret_cast<u64 *>(base + o_ek);
             w.dscale = reinterpret_cast<float *>(base + o_ds);
+            w.bsum = reinterpret_cast<unsigned *>(base + o_bs);
             if (quarters) w.subk = reinterpret_cast<float *>(base + o_sk);
         }
     }
@@ -1063,6 +1068,7 @@ int fft_setup(const Geom &g, const Workspace &w, const float *du, int flags, hip
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemsetAsync(w.overflow, 0, (size_t)g.B * sizeof(int), st));
     HIP_TRY(hipMemsetAsync(w.ekeys, 0, (size_t)g.B * (MAXCONT + 1) * sizeof(u64), st));
+    HIP_TRY(hipMemsetAsync(w.bsum, 0, (size_t)g.B * g.NBLK * 2 * sizeof(unsigned), st));
     HIP_TRY(hipMemsetAsync(w.keys, 0, (size_t)g.B * n_cells * sizeof(u64), st));
     MP_FFT_DISPATCH(f.logM, {
         if ((rc = fft_lds_attr(fft_dict_kernel<LG>, lds))) return rc;
@@ -1094,7 +1100,7 @@ int fft_iteration(const Geom &g, const Workspace &w, const float *du, int K, int
     // MP_FLAG_FFT_FUSED / MP_FLAG_FFT_UNFUSED force either form.  A team of workgroups per segment inside
     // one kernel was tried and dropped: agent-scope fences between its members cost 3-13 us each.
     const bool fused = !(flags & MP_FLAG_REFINE_MFMA) && !(flags & MP_FLAG_FFT_UNFUSED) &&
-                       ((flags & MP_FLAG_FFT_FUSED) || n_cells >= 65536);
+                       ((flags & MP_FLAG_FFT_FUSED) || n_cells >= FUSED_MIN_CELLS);
     // both forms leave the next step's window spectrum behind when the screen's register transform exists
     // for this size (the stand-alone window kernel then runs before the first step only)
     // ... or, for small segments, ONE kernel that refines only a quarter of a contender cell (needs the screen's
@@ -1109,6 +1115,8 @@ int fft_iteration(const Geom &g, const Workspace &w, const float *du, int K, int
                          ((flags & MP_FLAG_FFT_QUARTER) || !((flags & MP_FLAG_INTERNAL_ONE_STREAM) && two_launch_ok));
     const bool b_tail = !fused && !quarter && !(flags & MP_FLAG_FFT_SIMPLE) && f.logM >= 10 && f.logM <= 12;
     const bool fused_tail = (fused && f.logM >= 10) || b_tail || quarter;
+    // (kept up to date by fft_screen_kernel only: not with the plain radix-4 screen)
+    unsigned *bsum = (fused && n_cells >= FUSED_MIN_CELLS && f.logM >= 10 && !(flags & MP_FLAG_FFT_SIMPLE)) ? w.bsum : nullptr;
     {
         const int *dirty = k == 0 ? nullptr : w.dirty;
         const int nw = k == 0 ? f.NW : 1;
@@ -1140,7 +1148,7 @@ int fft_iteration(const Geom &g, const Workspace &w, const float *du, int K, int
                 const dim3 grid = seg_fast ? dim3((unsigned)g.B, gwp, g.NAT) : dim3(gwp, g.NAT, (unsigned)g.B);
                 if ((rc = fft_lds_attr(fft_screen_kernel<LS>, lds_s))) return rc;
                 hipLaunchKernelGGL(fft_screen_kernel<LS>, grid, dim3(C::WG), lds_s, st, w.xspec, w.pspec, w.tw, dirty,
-                                   w.wnorm, w.keys, w.ceps, g.N, g.A, g.NBLK, g.NAT, f.V, f.NW, FFT_TAU, pps, (int)seg_fast, subk);
+                                   w.wnorm, w.keys, w.ceps, g.N, g.A, g.NBLK, g.NAT, f.V, f.NW, FFT_TAU, pps, (int)seg_fast, subk, bsum);
             } else {
                 hipLaunchKernelGGL(fft_correlate_kernel<LG>, dim3(nw, g.NAT, (unsigned)g.B), dim3(256), lds, st,
                                    w.xspec, w.pspec, w.tw, dirty, w.wnorm, w.keys, w.ceps, g.N, g.A, g.NBLK,
@@ -1170,7 +1178,7 @@ int fft_iteration(const Geom &g, const Workspace &w, const float *du, int K, int
                 hipLaunchKernelGGL(fft_select_fused_kernel<LT>, dim3((unsigned)g.B), dim3(1024), lds_f, st, w.keys,
                                    w.ceps, n_cells, w.res, du, w.dirty, w.overflow, out_atom, out_lag, out_gain,
                                    g.N, g.A, g.L, g.Ns, g.NBLK, g.NAT, K, k, rule.du_sub, rule.shift, rule.square,
-                                   w.tw, w.xspec, w.wnorm, f.NW, (const float *)w.dscale);
+                                   w.tw, w.xspec, w.wnorm, f.NW, (const float *)w.dscale, bsum);
             })
         } else {
             // select-A merged into the refinement launch when select-B is the kernel that clears the slots
@@ -1259,6 +1267,7 @@ Workspace sub_batch(const Workspace &w, const Geom &g, int path, int64_t b0, int
         v.overflow = w.overflow + b0;
         v.ekeys = w.ekeys + b0 * (MAXCONT + 1);
         if (w.subk) v.subk = w.subk + b0 * cells * SUBCELLS;
+        v.bsum = w.bsum + b0 * g.NBLK * 2;
     }
     return v;
 }
