@@ -57,7 +57,7 @@ extern "C" {
 #define MP_FLAG_FFT_FUSED 1024  /* MP_PATH_FFT: the whole-cell one-kernel select (default only for >= 65536 cells per
                                    segment)                                                                        */
 #define MP_FLAG_OVERLAP 2048    /* sub-batches on forked internal streams (joined before returning); default for
-                                   MP_PATH_FFT from 32 segments of < 65536 cells up                               */
+                                   MP_PATH_FFT from 64 segments of < 65536 cells up                               */
 #define MP_FLAG_NO_OVERLAP 4096 /* never split the batch                                                          */
 #define MP_FLAG_FFT_NO_QUARTER 8192 /* MP_PATH_FFT: segments of <= 16384 cells through scan+refine / select-B instead
                                        of the one-kernel quarter-cell select (default when the batch is split)    */

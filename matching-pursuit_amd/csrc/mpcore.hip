@@ -1376,12 +1376,13 @@ static int encode_impl(const float *signal, int64_t B, int64_t N, const float *d
     // caller's stream before returning; fork/join by events is graph-capture safe.
     // Measured (scripts/fft_ab.py): FFT schedule, headline shape 5.49 -> 5.25 ms per encode with two
     // sub-batches; +1 % on the incremental MFMA schedule; -4 % at the config-4 shape, whose screens fill the
-    // GPU on their own.  Default for MP_PATH_FFT from 32 segments up when a segment has < 65536 cells
+    // GPU on their own, and -6..-20 % with 32 segments (half-batches of 16 are too small).  Default for
+    // MP_PATH_FFT from 64 segments up when a segment has < 65536 cells
     // (MP_FLAG_NO_OVERLAP turns it off), opt-in elsewhere (MP_FLAG_OVERLAP).
     int n_groups = 1;
     if (K > 0 && !(flags & MP_FLAG_NO_OVERLAP) &&
         (((flags & MP_FLAG_OVERLAP) && B >= 8) ||
-         (path == MP_PATH_FFT && B >= 32 && (int64_t)g.NBLK * g.NAT < 65536)))  // big screens fill the GPU alone
+         (path == MP_PATH_FFT && B >= 64 && (int64_t)g.NBLK * g.NAT < 65536)))  // big screens fill the GPU alone
         n_groups = overlap_groups >= 2 && overlap_groups <= MAX_GROUPS ? overlap_groups : 2;
     StreamPool *pool = nullptr;
     if (n_groups > 1) {
