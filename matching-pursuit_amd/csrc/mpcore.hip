@@ -1100,7 +1100,8 @@ int fft_iteration(const Geom &g, const Workspace &w, const float *du, int K, int
     // MP_FLAG_FFT_FUSED / MP_FLAG_FFT_UNFUSED force either form.  A team of workgroups per segment inside
     // one kernel was tried and dropped: agent-scope fences between its members cost 3-13 us each.
     const bool fused = !(flags & MP_FLAG_REFINE_MFMA) && !(flags & MP_FLAG_FFT_UNFUSED) &&
-                       ((flags & MP_FLAG_FFT_FUSED) || n_cells >= FUSED_MIN_CELLS);
+                       ((flags & MP_FLAG_FFT_FUSED) || n_cells >= FUSED_MIN_CELLS ||
+                        (n_cells > QUARTER_MAX_CELLS && g.L <= 512));  // mid sizes: only while a cell's chains are short
     // both forms leave the next step's window spectrum behind when the screen's register transform exists
     // for this size (the stand-alone window kernel then runs before the first step only)
     // ... or, for small segments, ONE kernel that refines only a quarter of a contender cell (needs the screen's
@@ -1116,7 +1117,7 @@ int fft_iteration(const Geom &g, const Workspace &w, const float *du, int K, int
     const bool b_tail = !fused && !quarter && !(flags & MP_FLAG_FFT_SIMPLE) && f.logM >= 10 && f.logM <= 12;
     const bool fused_tail = (fused && f.logM >= 10) || b_tail || quarter;
     // (kept up to date by fft_screen_kernel only: not with the plain radix-4 screen)
-    unsigned *bsum = (fused && n_cells >= FUSED_MIN_CELLS && f.logM >= 10 && !(flags & MP_FLAG_FFT_SIMPLE)) ? w.bsum : nullptr;
+    unsigned *bsum = (fused && n_cells > QUARTER_MAX_CELLS && f.logM >= 10 && !(flags & MP_FLAG_FFT_SIMPLE)) ? w.bsum : nullptr;
     {
         const int *dirty = k == 0 ? nullptr : w.dirty;
         const int nw = k == 0 ? f.NW : 1;
