@@ -21,6 +21,8 @@ marked = 0
 for case in range(n_cases):
     A = int(rng.integers(1, 90)); L = int(rng.choice([5, 16, 33, 64, 100, 128, 250, 300, 512, 700, 1100]))
     N = int(rng.integers(max(L // 2, 40), 9000)); B = int(rng.choice([1, 2, 3, 7, 31, 32, 33, 45, 70])); K = int(rng.integers(1, 10))
+    if case % 10 == 3:   # more than 16384 cells per segment: the block-summary select (short atoms) / the four-kernel form
+        A = int(rng.choice([1000, 1024, 1500])); L = int(rng.choice([32, 64, 600])); N = int(rng.integers(36000, 48000)); B = 2; K = 3
     d = synth.make_dictionary(A, L, seed=1000 + case)
     x = synth.make_segments(B, N, d, n_events=min(3 * K, 12), seed=5000 + case) if N > L else \
         rng.standard_normal((B, N)).astype(np.float32)
