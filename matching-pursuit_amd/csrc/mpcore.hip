@@ -151,23 +151,38 @@ __device__ inline u64 wave_max_u64(u64 k) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// unit_norm  (modules/normalization.py:4-6): one thread per atom, fp64 sequential sum of squares so
-// that the CPU oracle reproduces it bit for bit.  A*L is tiny next to one correlation.
+// unit_norm  (modules/normalization.py:4-6): one wavefront per atom, sum of squares in fp64 in a fixed order
+// (64 interleaved partial sums, then their sum) that the CPU oracle reproduces bit for bit.
 // ------------------------------------------------------------------------------------------------
-__global__ void unit_norm_kernel(const float *__restrict__ d, int64_t A, int64_t L, float eps,
-                                 float *__restrict__ out) {
-    int64_t a = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+// Correctly rounded fp32 square root, whatever the compiler makes of sqrtf / __fsqrt_rn (the latter is
+// __ocml_native_sqrt_f32 in this toolchain, and whether it got the 1-ulp v_sqrt_f32 alone or its refinement depended
+// on the surrounding code): fp64 sqrt is correctly rounded and 53 >= 2 * 24 + 2 bits make the second rounding exact.
+__device__ __forceinline__ float sqrt_rn_f32(float x) { return (float)sqrt((double)x); }
+__device__ __forceinline__ float div_rn_f32(float a, float b) { return (float)((double)a / (double)b); }  // likewise
+
+// sum of squares of a row in fp64 by one wavefront: lane j sums samples j, j + 64, ... in ascending order, then
+// every lane adds the 64 partials in ascending order (the oracle's order, oracle/mp_oracle.c::mpo_unit_norm)
+__device__ __forceinline__ double row_sum_squares(const float *row, int64_t L, int lane) {
+    double p = 0.0;
+    for (int64_t k = lane; k < L; k += 64) {
+        const double x = (double)row[k];
+        p += x * x;
+    }
+    double s = 0.0;
+    for (int j = 0; j < 64; ++j) s += __shfl(p, j, 64);
+    return s;
+}
+__global__ __launch_bounds__(256) void unit_norm_kernel(const float *__restrict__ d, int64_t A, int64_t L, float eps,
+                                                        float *__restrict__ out) {
+    const int lane = threadIdx.x & 63;
+    const int64_t a = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);  // one wavefront per row
     if (a >= A) return;
     const float *row = d + a * L;
-    double s = 0.0;
-    for (int64_t k = 0; k < L; ++k) {
-        double x = (double)row[k];
-        s += x * x;
-    }
-    float n = __fsqrt_rn((float)s);
-    float den = __fadd_rn(n, eps);
+    const double s = row_sum_squares(row, L, lane);
+    const float n = sqrt_rn_f32((float)s);
+    const float den = __fadd_rn(n, eps);
     float *orow = out + a * L;
-    for (int64_t k = 0; k < L; ++k) orow[k] = __fdiv_rn(row[k], den);
+    for (int64_t k = lane; k < L; k += 64) orow[k] = div_rn_f32(row[k], den);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -761,19 +776,15 @@ __global__ __launch_bounds__(1024) void dictionary_update_kernel(
             nw[j] = (float)acc;
         }
         __syncthreads();
-        if (tid == 0) {
-            double ss = 0.0;
-            for (int64_t j = 0; j < L; ++j) {
-                const double x = (double)nw[j];
-                ss += x * x;
-            }
-            s_den = __fadd_rn(__fsqrt_rn((float)ss), eps);
+        if (tid < 64) {  // the first wavefront: unit_norm_kernel's arithmetic
+            const double ss = row_sum_squares(nw, L, tid);
+            if (tid == 0) s_den = __fadd_rn(sqrt_rn_f32((float)ss), eps);
         }
         __syncthreads();
         const float den = s_den;
         float *drow = d_work + order[g] * L;
         for (int64_t j = tid; j < L; j += 1024) {
-            const float v = __fdiv_rn(nw[j], den);
+            const float v = div_rn_f32(nw[j], den);
             nw[j] = v;
             drow[j] = v;
         }
@@ -1326,8 +1337,7 @@ int mp_profile_read(double *ms, int64_t *count) {
 int mp_unit_norm_f32(const float *d, int64_t A, int64_t L, float eps, float *out, void *stream) {
     if (!d || !out || A <= 0 || L <= 0) return fail(MP_ERR_ARG, "mp_unit_norm_f32: bad arguments%s");
     hipStream_t st = static_cast<hipStream_t>(stream);
-    hipLaunchKernelGGL(unit_norm_kernel, dim3((unsigned)((A + 63) / 64)), dim3(64), 0, st, d, A, L, eps,
-                       out);
+    hipLaunchKernelGGL(unit_norm_kernel, dim3((unsigned)((A + 3) / 4)), dim3(256), 0, st, d, A, L, eps, out);
     HIP_TRY(hipGetLastError());
     return MP_OK;
 }

@@ -25,7 +25,8 @@
  *   - argmax is over the SIGNED value, first occurrence in flat order a*N + t (torch.max).
  *   - subtraction is two roundings, r = r - (d*g), never an fma (the reference forms
  *     `at = d[atom] * value` first, :305) and is cropped at N, gain not renormalised.
- *   - unit_norm: sum of squares accumulated sequentially in fp64 (products of two floats
+ *   - unit_norm: sum of squares accumulated in fp64, 64 interleaved partial sums then their sum, each in
+ *     ascending order (products of two floats
  *     are exact in fp64), rounded once to fp32, sqrtf, then x / (n + eps) in fp32.
  *
  * Pinned against the real reference by tests/golden/ (see tests/golden/generate_golden.py):
@@ -64,10 +65,17 @@ void mpo_set_num_threads(int n) {
 /* modules/normalization.py:4-6 : x / (||x||_2 + eps) along the last axis */
 int mpo_unit_norm(const float *d, int64_t A, int64_t L, float eps, float *out) {
     for (int64_t a = 0; a < A; ++a) {
+        /* 64 interleaved partial sums (partial j: samples j, j + 64, ... in ascending order), then the partials
+         * in ascending order: the order a 64-lane wavefront produces, so the GPU kernel can use all its lanes
+         * and still match bit for bit */
         double s = 0.0;
-        for (int64_t k = 0; k < L; ++k) {
-            double x = (double)d[a * L + k];
-            s += x * x;
+        for (int j = 0; j < 64; ++j) {
+            double p = 0.0;
+            for (int64_t k = j; k < L; k += 64) {
+                double x = (double)d[a * L + k];
+                p += x * x;
+            }
+            s += p;
         }
         float n = sqrtf((float)s);
         float den = n + eps;
