@@ -26,6 +26,14 @@ for case in range(n_cases):
     d = synth.make_dictionary(A, L, seed=1000 + case)
     x = synth.make_segments(B, N, d, n_events=min(3 * K, 12), seed=5000 + case) if N > L else \
         rng.standard_normal((B, N)).astype(np.float32)
+    if case % 10 == 6:   # duplicated atoms: exact ties between atoms, settled by the lower flat index
+        d[A // 2:] = d[: A - A // 2]
+    if case % 10 == 7 and N > 4 * L:   # a periodic train of one atom: many equal or near-equal maxima
+        x = np.zeros((B, N), dtype=np.float32)
+        for p0 in range(0, N - L, 2 * L):
+            x[:, p0:p0 + L] += d[0] / np.linalg.norm(d[0])
+    if case % 10 == 8:   # tiny and huge amplitudes
+        x = (x * (1e-30 if case % 20 == 8 else 1e18)).astype(np.float32)
     du = mp_oracle.unit_norm(d)
     want = mp_oracle.encode(x, du, K)
     gap = (want["top2"][..., 0] - want["top2"][..., 1]) / np.maximum(np.abs(want["top2"][..., 0]), 1e-30)

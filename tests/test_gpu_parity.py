@@ -343,3 +343,19 @@ def test_fft_screen_bound_follows_the_dictionary_norm(oracle):
         assert not np.isnan(gain).any()
         assert np.array_equal(atom, want["atom"]) and np.array_equal(lag, want["lag"])
         assert np.array_equal(gain, want["gain"]) and np.array_equal(res, want["residual"])
+
+
+@pytest.mark.parametrize("scale", [1e-30, 1e-36, 1e18])
+def test_fft_screen_survives_extreme_amplitudes(oracle, scale):
+    """Samples around 1e-30 have squares that underflow in fp32: a window norm computed in fp32 would read zero,
+    the window would pass for all-zero ("exact") and the screen's approximate keys would be trusted.  The norm is
+    accumulated in fp64; 1e18 (squares near overflow) must not turn the bound into infinity either."""
+    du = oracle.unit_norm(synth.make_dictionary(40, 96, seed=14))
+    x = (synth.make_segments(4, 3000, du, n_events=10, seed=15) * scale).astype(np.float32)
+    want = oracle.encode(x, du, 5)
+    for flags in (0, nat.MP_FLAG_FFT_QUARTER, nat.MP_FLAG_FFT_FUSED, nat.MP_FLAG_FFT_UNFUSED):
+        atom, lag, gain, res = _gpu_encode(x, du, 5, nat.MP_PATH_FFT, flags)
+        keep = ~np.isnan(gain).any(axis=1)
+        assert keep.all()
+        assert np.array_equal(atom, want["atom"]) and np.array_equal(lag, want["lag"])
+        assert np.array_equal(gain, want["gain"]) and np.array_equal(res, want["residual"])
