@@ -21,6 +21,10 @@ marked = 0
 for case in range(n_cases):
     A = int(rng.integers(1, 90)); L = int(rng.choice([5, 16, 33, 64, 100, 128, 250, 300, 512, 700, 1100]))
     N = int(rng.integers(max(L // 2, 40), 9000)); B = int(rng.choice([1, 2, 3, 7, 31, 32, 33, 45, 70])); K = int(rng.integers(1, 10))
+    if case % 10 == 1:   # degenerate sizes: one-sample atoms, segments shorter than a block, a single atom
+        A = int(rng.choice([1, 2, 33])); L = int(rng.choice([1, 2, 3])); N = int(rng.integers(1, 70)); B = int(rng.choice([1, 3, 40]))
+    if case % 10 == 2:   # many more steps than the segment has structure: the tail of the run is rounding noise
+        A = int(rng.integers(2, 20)); L = int(rng.choice([8, 32])); N = int(rng.integers(100, 600)); B = 3; K = 40
     if case % 10 == 3:   # more than 16384 cells per segment: the block-summary select (short atoms) / the four-kernel form
         A = int(rng.choice([1000, 1024, 1500])); L = int(rng.choice([32, 64, 600])); N = int(rng.integers(36000, 48000)); B = 2; K = 3
     d = synth.make_dictionary(A, L, seed=1000 + case)
