@@ -59,5 +59,23 @@ for case in range(n_cases):
             print(f"MISMATCH case {case} {name}: A{A} L{L} N{N} B{B} K{K} min top-2 gap {gap.min():.2e}", flush=True)
     if case % 10 == 9:
         print(f"{case + 1} cases done, {bad} mismatches", flush=True)
+# the convolution model of mp.py (raw atoms, v^2 update, no oracle): its three schedules must agree with each other
+conv_bad = 0
+for case in range(max(n_cases // 5, 4)):
+    A = int(rng.integers(2, 70)); L = int(rng.choice([8, 32, 100, 128])); N = int(rng.integers(2 * L, 5000))
+    B = int(rng.choice([1, 3, 33])); K = int(rng.integers(1, 6))
+    atoms = (synth.make_dictionary(A, L, seed=9000 + case) * 0.2).astype(np.float32)
+    x = synth.make_segments(B, N, synth.make_dictionary(A, L, seed=9000 + case), n_events=8, seed=9500 + case)
+    xd = torch.from_numpy(x).cuda(); ad = torch.from_numpy(atoms).cuda()
+    ref = nat.encode(xd, ad, K, path=nat.MP_PATH_DIRECT, conv_model=True)
+    for name, path, flags in (("incremental", nat.MP_PATH_INCREMENTAL, 0), ("fft", nat.MP_PATH_FFT, 0),
+                              ("fft_quarter", nat.MP_PATH_FFT, nat.MP_FLAG_FFT_QUARTER), ("fft_fused", nat.MP_PATH_FFT, nat.MP_FLAG_FFT_FUSED)):
+        out = nat.encode(xd, ad, K, path=path, flags=flags, conv_model=True)
+        keep = ~torch.isnan(out[2]).any(dim=1)
+        if not all(torch.equal(a[keep], b[keep]) for a, b in zip(out, ref)):
+            conv_bad += 1
+            print(f"CONV MISMATCH case {case} {name}: A{A} L{L} N{N} B{B} K{K}", flush=True)
+print("convolution-model schedules agree:", "OK" if conv_bad == 0 else f"{conv_bad} MISMATCHES", flush=True)
+bad += conv_bad
 print("fuzz parity:", "OK" if bad == 0 else f"{bad} MISMATCHES", f"({marked} segment-runs marked as screen overflow)", flush=True)
 sys.exit(1 if bad else 0)
