@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Randomised parity sweep: the default schedule (and a few others) against the CPU oracle, bitwise, on shapes
 no fixed test uses -- odd atom counts, atoms longer than the segment's tail, batches that split unevenly
-into sub-batches, segments shorter than one transform.   fuzz_parity.py [n_cases] [seed]"""
+into sub-batches, segments shorter than one transform.  Lives under tests/ because it uses the oracle (test
+infrastructure); not collected by pytest -- run it by hand:   python tests/fuzz_parity.py [n_cases] [seed]"""
 import os, sys
 import numpy as np, torch
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

@@ -309,7 +309,7 @@ def test_fft_batches_above_the_per_call_limit_are_chunked(monkeypatch):
 
 
 def test_random_shapes_default_schedule_is_bitwise(oracle):
-    """A short run of scripts/fuzz_parity.py's sweep: shapes no fixed case uses (odd atom counts, batches that
+    """A short run of tests/fuzz_parity.py's sweep: shapes no fixed case uses (odd atom counts, batches that
     split unevenly into sub-batches, segments shorter than one transform), default schedule vs oracle."""
     rng = np.random.default_rng(31337)
     for case in range(12):
