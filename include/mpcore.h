@@ -111,6 +111,8 @@ int mp_unit_norm_f32(const float *d, int64_t A, int64_t L, float eps, float *out
  *   out_gain   [B, K]   out  value of the feature map at the argmax (the event's gain)
  *   out_residual [B, N] out  residual after K steps, or NULL
  *   workspace           >= mp_workspace_bytes(...) bytes, 256-byte aligned
+ * Asynchronous on `stream`.  MP_PATH_FFT may run parts of a large batch on internal streams forked from and
+ * joined back into `stream` by events (MP_FLAG_NO_OVERLAP: never); the caller sees ordinary stream order.
  */
 int mp_encode_f32(const float *signal, int64_t B, int64_t N, const float *dict_unit, int64_t A,
                   int64_t L, int K, int path, int flags, int64_t *out_atom, int64_t *out_lag,
