@@ -4,6 +4,6 @@ from ._native import NativeError  # noqa: F401
 from .matchingpursuit import (  # noqa: F401
     build_scatter_segments, flatten_atom_dict, sparse_code, dictionary_learning_step,
     sparse_feature_map, sparse_coding_loss, SparseCodingLoss, unit_norm, torch_conv, fft_convolve,
-    EventList, encode_packed)
+    EventList, encode_packed, sparse_feature_map_coo)
 from .iterative import iterative_loss, sort_channels_descending_norm  # noqa: F401
 from .streaming import encode_streaming, decode_streaming, StreamCode  # noqa: F401

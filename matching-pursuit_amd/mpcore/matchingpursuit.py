@@ -548,8 +548,39 @@ def sparse_feature_map(signal, d, n_steps=100, device=None, approx=None, pooling
     return fm
 
 
+def sparse_feature_map_coo(signal, d, n_steps=100):
+    """The nonzero entries of sparse_feature_map (:68-125) without the dense [B, A, N] map (4 GiB at the
+    headline shape): (flat index b * A * N + a * N + p, value) with repeated picks of one (atom, lag)
+    accumulated, sorted by index, plus the map's shape.  No gradient."""
+    signal = signal.view(signal.shape[0], 1, -1)
+    batch, _, n_samples = signal.shape
+    n_atoms = d.shape[0]
+    dev = _compute_device(signal)
+    with torch.no_grad():
+        d_unit = _native.unit_norm(d.detach().to(dev))
+        atom, lag, gain, _ = _native.encode_checked(signal.detach().to(dev, torch.float32)[:, 0, :], d_unit, n_steps,
+                                                    want_residual=False)
+        bidx = torch.arange(batch, device=dev)[:, None].expand_as(atom)
+        flat = ((bidx * n_atoms + atom) * n_samples + lag).reshape(-1)
+        idx, inv = torch.unique(flat, return_inverse=True)
+        val = torch.zeros(idx.shape[0], device=dev).index_add_(0, inv, gain.reshape(-1))
+    return idx, val, (batch, n_atoms, n_samples)
+
+
 def sparse_coding_loss(recon, target, d, n_steps=100, device=None, approx=None, pooling=None):
-    """modules/matchingpursuit.py:128-146."""
+    """modules/matchingpursuit.py:128-146.  When no gradient is wanted the loss is evaluated on the maps' nonzero
+    entries only (every other cell contributes bce(0, 0) = 0), without ever building the dense maps."""
+    if not (torch.is_grad_enabled() and recon.requires_grad):
+        ri, rv, shape = sparse_feature_map_coo(recon, d, n_steps)
+        ti, tv, _ = sparse_feature_map_coo(target, d, n_steps)
+        mx = max(rv.max().item(), tv.max().item())
+        idx = torch.unique(torch.cat([ri, ti]))
+        r = torch.zeros(idx.shape[0], device=rv.device)
+        t = torch.zeros(idx.shape[0], device=rv.device)
+        r[torch.searchsorted(idx, ri)] = rv / mx
+        t[torch.searchsorted(idx, ti)] = tv / mx
+        total = F.binary_cross_entropy(r, t, reduction="sum")
+        return (total / float(shape[0] * shape[1] * shape[2])).to(recon.device)
     r_map = sparse_feature_map(recon, d, n_steps, device=device, pooling=pooling)
     with torch.no_grad():
         t_map = sparse_feature_map(target, d, n_steps, device=device, pooling=pooling)

@@ -147,8 +147,15 @@ def test_sparse_feature_map_matches_reference(golden_dir):
     vals = fm[nz[:, 0], nz[:, 1], nz[:, 2]].cpu().numpy()
     assert np.abs(vals - z["nz_value"]).max() <= 1e-5 * np.abs(z["nz_value"]).max()
     assert np.abs(res[:, 0].cpu().numpy() - z["residual"]).max() <= REL * np.abs(z["signal"]).max()
-    loss = mp.sparse_coding_loss(x * 0.9, x, d, n_steps=4)
+    loss = mp.sparse_coding_loss(x * 0.9, x, d, n_steps=4)   # no gradient wanted: evaluated on the nonzero entries
     assert torch.isfinite(loss)
+    recon = (x * 0.9).requires_grad_(True)                  # gradient wanted: the dense maps, as the reference
+    dense = mp.sparse_coding_loss(recon, x, d, n_steps=4)
+    assert abs(loss.item() - dense.item()) <= 1e-6 * abs(dense.item()) + 1e-12
+    from mpcore import sparse_feature_map_coo
+    idx, val, shape = sparse_feature_map_coo(x, d, n_steps=int(z["n_steps"]))
+    flat = fm.reshape(-1)
+    assert shape == tuple(fm.shape) and torch.equal(torch.nonzero(flat).flatten(), idx) and torch.equal(flat[idx], val)
 
 
 def test_sparse_feature_map_gradient_matches_reference(golden_dir):
