@@ -674,12 +674,6 @@ __global__ __launch_bounds__(256) void select_subtract_kernel(
     for (int64_t s = tid; s < len; s += 256) r[s] = __fsub_rn(r[s], __fmul_rn(d[s], g2));
 }
 
-__global__ void fill_dirty_kernel(int *dirty, int64_t B, int first, int count) {
-    int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (b < B) {
-        dirty[2 * b] = first;
-        dirty[2 * b + 1] = count;
-    }
 }
 
 // ------------------------------------------------------------------------------------------------
