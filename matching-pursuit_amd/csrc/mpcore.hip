@@ -674,8 +674,6 @@ __global__ __launch_bounds__(256) void select_subtract_kernel(
     for (int64_t s = tid; s < len; s += 256) r[s] = __fsub_rn(r[s], __fmul_rn(d[s], g2));
 }
 
-}
-
 // ------------------------------------------------------------------------------------------------
 // scatter_segments (modules/matchingpursuit.py:20-58): one workgroup per segment walks the event
 // list in order; events of a segment may overlap, so they are applied one after another.
