@@ -135,6 +135,22 @@ int mp_encode_conv_f32(const float *signal, int64_t B, int64_t N, const float *a
                        void *stream);
 
 /*
+ * mp_encode_f32 with the reference's local-contrast-norm selection rule,
+ * sparse_code(..., local_contrast_norm=True), modules/matchingpursuit.py:284-294 (and
+ * dictionary_learning_step(local_constrast_norm=True), :361-363): each step selects the argmax of
+ *   fm - avg_pool2d(fm, (9, 9), stride 1, padding 4)      over the dense (A, N) map
+ * (zero padding, every window divided by 81) and reports the RAW map value there as the gain (:294).
+ * The box mean is one sequential fp32 sum in row-major window order, as ATen computes it on the CPU, so
+ * selections are bit-identical to the reference's.  The dense map lives in the workspace ([B, A, N] floats:
+ * size the batch accordingly) and only the 64-lag blocks an event dirties are recomputed per step.
+ * Arguments as mp_encode_f32; workspace >= mp_lcn_workspace_bytes(...), 256-byte aligned; B <= 65535.
+ */
+size_t mp_lcn_workspace_bytes(int64_t B, int64_t N, int64_t A, int64_t L, int K);
+int mp_encode_lcn_f32(const float *signal, int64_t B, int64_t N, const float *dict_unit, int64_t A, int64_t L,
+                      int K, int64_t *out_atom, int64_t *out_lag, float *out_gain, float *out_residual,
+                      void *workspace, size_t workspace_bytes, void *stream);
+
+/*
  * Dense feature map fm[b, a, t] = sum_k r[b, t+k] * d[a, k]  (r zero beyond N), t in [0, N).
  * Replaces F.conv1d(F.pad(residual,(0,L)), d.view(A,1,L))[..., :N]
  * (modules/matchingpursuit.py:275-277, :90-92; modules/conv.py:4-9).  Serves the hooks that

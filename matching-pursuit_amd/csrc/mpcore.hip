@@ -675,6 +675,114 @@ __global__ __launch_bounds__(256) void select_subtract_kernel(
 }
 
 // ------------------------------------------------------------------------------------------------
+// Local contrast norm (modules/matchingpursuit.py:284-294): the step's event is the argmax of
+//   lcn[a,t] = fm[a,t] - avg_pool2d(fm, 9x9, stride 1, zero pad 4, count_include_pad)[a,t]
+// over the dense (A, N) map, and its gain is the RAW map value there (:294).  avg is ONE sequential fp32 sum
+// over the window in row-major order (a' ascending, then t' ascending; zeros outside the map add nothing)
+// divided by 81 -- ATen's cpu_avg_pool2d loop, restated in oracle/mp_oracle.c:mpo_encode_lcn.
+// The map itself is kept in HBM and only its dirty 64-lag blocks are recomputed each step (the MFMA
+// correlate with STORE_FM); this kernel then redoes the LCN keys of those blocks and one block either side
+// (the box reaches 4 lags across a block edge).  One workgroup = one LCN cell of 16 atoms x 64 lags, staged
+// with its halo (24 x 72 floats) in LDS; a wavefront's 64 lanes read 64 consecutive floats of one row, so the
+// 81 LDS reads per output are conflict-free.
+// ------------------------------------------------------------------------------------------------
+constexpr int LCN_TA = 16;
+constexpr int LCN_W = LAGS_PER_WAVE + 8;
+
+__global__ __launch_bounds__(256) void lcn_keys_kernel(const float *__restrict__ fm, const int *__restrict__ dirty,
+                                                       u64 *__restrict__ lkeys, int64_t N, int64_t A, int NBLK,
+                                                       int NLT) {
+    __shared__ float tile[LCN_TA + 8][LCN_W + 1];
+    __shared__ u64 s_key[4];
+    const int b = blockIdx.z;
+    const int atile = blockIdx.y;
+    int first = 0, last = NBLK - 1;
+    if (dirty) {
+        first = dirty[2 * b] - 1;
+        last = dirty[2 * b] + dirty[2 * b + 1];
+        if (first < 0) first = 0;
+        if (last > NBLK - 1) last = NBLK - 1;
+    }
+    const int blk = first + blockIdx.x;
+    if (blk > last) return;  // uniform across the workgroup
+    const int tid = threadIdx.x;
+    const int64_t a0 = (int64_t)atile * LCN_TA - 4, t0 = (int64_t)blk * LAGS_PER_WAVE - 4;
+    const float *fb = fm + (int64_t)b * A * N;
+    for (int e = tid; e < (LCN_TA + 8) * LCN_W; e += 256) {
+        const int r = e / LCN_W, c = e - r * LCN_W;
+        const int64_t a = a0 + r, t = t0 + c;
+        tile[r][c] = (a >= 0 && a < A && t >= 0 && t < N) ? fb[a * N + t] : 0.0f;
+    }
+    __syncthreads();
+    const int w = tid >> 6, lane = tid & 63;
+    u64 best = 0;
+#pragma unroll
+    for (int j = 0; j < LCN_TA / 4; ++j) {
+        const int ra = w * (LCN_TA / 4) + j;  // row of the cell; tile row ra + 4 is its centre
+        float sum = 0.0f;
+#pragma unroll
+        for (int da = 0; da < 9; ++da)
+#pragma unroll
+            for (int dt = 0; dt < 9; ++dt) sum = __fadd_rn(sum, tile[ra + da][lane + dt]);
+        const float v = __fsub_rn(tile[ra + 4][lane + 4], div_rn_f32(sum, 81.0f));
+        const int64_t a = a0 + 4 + ra, t = t0 + 4 + lane;
+        const u64 key = (a < A && t < N) ? make_key(v, (unsigned)(a * N + t)) : 0ull;
+        best = key > best ? key : best;
+    }
+    best = wave_max_u64(best);
+    if (lane == 0) s_key[w] = best;
+    __syncthreads();
+    if (tid == 0) {
+#pragma unroll
+        for (int q = 1; q < 4; ++q) best = s_key[q] > best ? s_key[q] : best;
+        lkeys[((int64_t)b * NBLK + blk) * NLT + atile] = best;
+    }
+}
+
+// argmax over a segment's LCN keys; the gain is read from the raw map; then as select_subtract_kernel
+__global__ __launch_bounds__(256) void lcn_select_subtract_kernel(
+    const u64 *__restrict__ lkeys, int64_t n_keys, const float *__restrict__ fm, float *__restrict__ res,
+    const float *__restrict__ du, int *__restrict__ dirty, int64_t *__restrict__ out_atom,
+    int64_t *__restrict__ out_lag, float *__restrict__ out_gain, int64_t N, int64_t A, int64_t L, int64_t Ns,
+    int K, int k) {
+    __shared__ u64 s_key[4];
+    const int b = blockIdx.x;
+    const int tid = threadIdx.x;
+    const u64 *kb = lkeys + (int64_t)b * n_keys;
+    u64 best = 0;
+    for (int64_t e = tid; e < n_keys; e += 256) {
+        u64 v = kb[e];
+        best = v > best ? v : best;
+    }
+    best = wave_max_u64(best);
+    if ((tid & 63) == 0) s_key[tid >> 6] = best;
+    __syncthreads();
+    best = s_key[0];
+#pragma unroll
+    for (int q = 1; q < 4; ++q) best = s_key[q] > best ? s_key[q] : best;
+    const unsigned flat = 0xffffffffu - (unsigned)(best & 0xffffffffull);
+    const float gain = fm[(int64_t)b * A * N + flat];  // torch.gather(fm, index=mx), :294
+    const int64_t atom = (int64_t)(flat / (u64)N);
+    const int64_t lag = (int64_t)(flat % (u64)N);
+    __syncthreads();  // every thread has read the map before the residual (not the map) changes: no hazard,
+                      // but keep the order explicit for the next launch's readers
+    if (tid == 0) {
+        out_atom[(int64_t)b * K + k] = atom;
+        out_lag[(int64_t)b * K + k] = lag;
+        out_gain[(int64_t)b * K + k] = gain;
+        int64_t lo = lag - L + 1; if (lo < 0) lo = 0;
+        int64_t hi = lag + L - 1; if (hi > N - 1) hi = N - 1;
+        const int fb = (int)(lo / LAGS_PER_WAVE), lb = (int)(hi / LAGS_PER_WAVE);
+        dirty[2 * b] = fb;
+        dirty[2 * b + 1] = lb - fb + 1;
+    }
+    const int64_t len = (N - lag) < L ? (N - lag) : L;
+    float *r = res + (int64_t)b * Ns + lag;
+    const float *d = du + atom * L;
+    for (int64_t s = tid; s < len; s += 256) r[s] = __fsub_rn(r[s], __fmul_rn(d[s], gain));
+}
+
+// ------------------------------------------------------------------------------------------------
 // scatter_segments (modules/matchingpursuit.py:20-58): one workgroup per segment walks the event
 // list in order; events of a segment may overlap, so they are applied one after another.
 // ------------------------------------------------------------------------------------------------
@@ -1463,6 +1571,66 @@ int mp_encode_conv_f32(const float *signal, int64_t B, int64_t N, const float *a
                        void *stream) {
     return encode_impl(signal, B, N, atoms, A, L, K, path, flags, out_atom, out_time, out_value, out_residual,
                        workspace, workspace_bytes, stream, true);
+}
+
+// sparse_code(..., local_contrast_norm=True), modules/matchingpursuit.py:284-294.  Workspace = the direct
+// path's + the dense map [B, A, N] + one LCN key per (64-lag block, 16-atom tile).
+static size_t lcn_extra(const Geom &g, size_t *o_map, size_t *o_keys, size_t base) {
+    const int NLT = (int)((g.A + LCN_TA - 1) / LCN_TA);
+    size_t off = (size_t)round_up((int64_t)base, 256);
+    *o_map = off;
+    off += (size_t)round_up((int64_t)((size_t)g.B * g.A * g.N * sizeof(float)), 256);
+    *o_keys = off;
+    off += (size_t)round_up((int64_t)((size_t)g.B * g.NBLK * NLT * sizeof(u64)), 256);
+    return off;
+}
+
+size_t mp_lcn_workspace_bytes(int64_t B, int64_t N, int64_t A, int64_t L, int K) {
+    if (check_shape(B, N, A, L, K) != MP_OK) return 0;
+    Geom g = make_geom(B, N, A, L, 32);
+    size_t o_map, o_keys;
+    return lcn_extra(g, &o_map, &o_keys, carve(g, MP_PATH_INCREMENTAL, nullptr).bytes);
+}
+
+int mp_encode_lcn_f32(const float *signal, int64_t B, int64_t N, const float *dict_unit, int64_t A, int64_t L,
+                      int K, int64_t *out_atom, int64_t *out_lag, float *out_gain, float *out_residual,
+                      void *workspace, size_t workspace_bytes, void *stream) {
+    int rc = check_shape(B, N, A, L, K);
+    if (rc) return rc;
+    if (B > 65535 || (A + LCN_TA - 1) / LCN_TA > 65535)
+        return fail(MP_ERR_ARG, "mp_encode_lcn_f32: B and A / 16 must be <= 65535%s");
+    if (B == 0) return MP_OK;
+    if (!signal || !dict_unit || !workspace) return fail(MP_ERR_ARG, "null pointer%s");
+    if (K > 0 && (!out_atom || !out_lag || !out_gain)) return fail(MP_ERR_ARG, "null output%s");
+    if (reinterpret_cast<uintptr_t>(workspace) % 256) return fail(MP_ERR_WORKSPACE, "workspace not 256-byte aligned%s");
+    Geom g = make_geom(B, N, A, L, 32);
+    char *base = static_cast<char *>(workspace);
+    Workspace w = carve(g, MP_PATH_INCREMENTAL, base);
+    size_t o_map, o_keys;
+    if (lcn_extra(g, &o_map, &o_keys, w.bytes) > workspace_bytes) return fail(MP_ERR_WORKSPACE, "workspace too small%s");
+    float *map = reinterpret_cast<float *>(base + o_map);
+    u64 *lkeys = reinterpret_cast<u64 *>(base + o_keys);
+    const int NLT = (int)((A + LCN_TA - 1) / LCN_TA);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if ((rc = stage_inputs(g, w, MP_PATH_INCREMENTAL, signal, dict_unit, 0, st))) return rc;
+    for (int k = 0; k < K; ++k) {
+        const int *dirty = k == 0 ? nullptr : w.dirty;
+        if ((rc = launch_correlate<true>(g, w, dirty, map, 0, st))) return rc;
+        const int nb = k == 0 ? g.NBLK : (g.MAXC + 2 < g.NBLK ? g.MAXC + 2 : g.NBLK);
+        hipLaunchKernelGGL(lcn_keys_kernel, dim3((unsigned)nb, (unsigned)NLT, (unsigned)B), dim3(256), 0, st, map,
+                           dirty, lkeys, N, A, g.NBLK, NLT);
+        HIP_TRY(hipGetLastError());
+        hipLaunchKernelGGL(lcn_select_subtract_kernel, dim3((unsigned)B), dim3(256), 0, st, lkeys,
+                           (int64_t)g.NBLK * NLT, map, w.res, dict_unit, w.dirty, out_atom, out_lag, out_gain, N, A, L,
+                           g.Ns, K, k);
+        HIP_TRY(hipGetLastError());
+    }
+    if (out_residual) {
+        dim3 grid((unsigned)((N + 255) / 256 < 1024 ? (N + 255) / 256 : 1024), (unsigned)B);
+        hipLaunchKernelGGL(copy_residual_kernel, grid, dim3(256), 0, st, w.res, N, g.Ns, out_residual, (int64_t)0);
+        HIP_TRY(hipGetLastError());
+    }
+    return MP_OK;
 }
 
 int mp_feature_map_f32(const float *residual, int64_t B, int64_t N, const float *dict_unit,

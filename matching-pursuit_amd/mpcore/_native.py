@@ -37,7 +37,7 @@ EXPORTS = (
     "mp_version", "mp_last_error", "mp_workspace_bytes", "mp_unit_norm_f32", "mp_encode_f32",
     "mp_feature_map_f32", "mp_scatter_f32", "mp_scatter_rows_f32", "mp_gather_sum_f32",
     "mp_profile_enable", "mp_profile_read", "mp_fft_c2c_f32", "mp_encode_conv_f32", "mp_tune",
-    "mp_dictionary_update_f32",
+    "mp_dictionary_update_f32", "mp_lcn_workspace_bytes", "mp_encode_lcn_f32",
 )
 
 _lib = None
@@ -62,6 +62,10 @@ def lib():
         L.mp_workspace_bytes.restype = ctypes.c_size_t
         L.mp_workspace_bytes.argtypes = [i64, i64, i64, i64, ctypes.c_int, ctypes.c_int]
         L.mp_unit_norm_f32.argtypes = [vp, i64, i64, fp, vp, vp]
+        L.mp_lcn_workspace_bytes.restype = ctypes.c_size_t
+        L.mp_lcn_workspace_bytes.argtypes = [i64, i64, i64, i64, ctypes.c_int]
+        L.mp_encode_lcn_f32.argtypes = [vp, i64, i64, vp, i64, i64, ctypes.c_int, vp, vp, vp, vp, vp,
+                                        ctypes.c_size_t, vp]
         L.mp_encode_f32.argtypes = [vp, i64, i64, vp, i64, i64, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                     vp, vp, vp, vp, vp, ctypes.c_size_t, vp]
         L.mp_encode_conv_f32.argtypes = L.mp_encode_f32.argtypes
@@ -202,6 +206,47 @@ def encode(signal, dict_unit, n_steps, path=MP_PATH_INCREMENTAL, flags=0, want_r
                                  ctypes.c_void_p(ws.data_ptr() + off), nbytes, _stream(signal))
     _check(rc, "mp_encode_conv_f32" if conv_model else "mp_encode_f32")
     # the workspace must outlive the asynchronous kernels: tie it to the stream
+    ws.record_stream(torch.cuda.current_stream(dev))
+    return atom, lag, gain, residual
+
+
+LCN_MAP_BYTES = 16 << 30  # the dense [B, A, N] map one mp_encode_lcn_f32 call may hold; larger batches are chunked
+
+
+def encode_lcn(signal, dict_unit, n_steps, want_residual=True):
+    """sparse_code(local_contrast_norm=True) (modules/matchingpursuit.py:284-294) -> as encode()."""
+    signal = _f32(signal)
+    dict_unit = _f32(dict_unit)
+    _require_cuda(signal, dict_unit)
+    B, N = signal.shape
+    A, L = dict_unit.shape
+    K = int(n_steps)
+    dev = signal.device
+    atom = torch.empty((B, K), dtype=torch.int64, device=dev)
+    lag = torch.empty((B, K), dtype=torch.int64, device=dev)
+    gain = torch.empty((B, K), dtype=torch.float32, device=dev)
+    residual = torch.empty((B, N), dtype=torch.float32, device=dev) if want_residual else None
+    if B == 0:
+        return atom, lag, gain, residual
+    chunk = max(1, min(FFT_MAX_BATCH, LCN_MAP_BYTES // (4 * A * N)))
+    if B > chunk:
+        for b0 in range(0, B, chunk):
+            sl = slice(b0, min(b0 + chunk, B))
+            a, l, g, r = encode_lcn(signal[sl], dict_unit, K, want_residual=want_residual)
+            atom[sl], lag[sl], gain[sl] = a, l, g
+            if want_residual:
+                residual[sl] = r
+        return atom, lag, gain, residual
+    nbytes = int(lib().mp_lcn_workspace_bytes(B, N, A, L, K))
+    if nbytes == 0:
+        raise NativeError(f"mp_lcn_workspace_bytes failed: {lib().mp_last_error().decode()}")
+    ws = torch.empty(nbytes + 256, dtype=torch.uint8, device=dev)
+    off = (-ws.data_ptr()) % 256
+    with torch.cuda.device(dev):
+        rc = lib().mp_encode_lcn_f32(_ptr(signal), B, N, _ptr(dict_unit), A, L, K, _ptr(atom), _ptr(lag),
+                                     _ptr(gain), _ptr(residual), ctypes.c_void_p(ws.data_ptr() + off), nbytes,
+                                     _stream(signal))
+    _check(rc, "mp_encode_lcn_f32")
     ws.record_stream(torch.cuda.current_stream(dev))
     return atom, lag, gain, residual
 

@@ -249,9 +249,12 @@ def sparse_code(
     approximate = isinstance(approx, slice) or (
         isinstance(approx, int) and not isinstance(approx, bool) and approx < n_samples)
     dense = (compute_feature_map is not None or extract_atom_embedding is not None or
-             visit_key_point is not None or local_contrast_norm or approximate)
+             visit_key_point is not None or approximate)
 
-    if dense:
+    if local_contrast_norm and not dense:  # :284-294 natively (mp_encode_lcn_f32)
+        atom, lag, gain, residual = _native.encode_lcn(signal.to(dev)[:, 0, :], d_unit, n_steps)
+        embeddings = None
+    elif dense:
         atom, lag, gain, residual, embeddings = _sparse_code_dense(
             signal.to(dev), d_unit, n_steps, approx if approximate else None, extract_atom_embedding,
             visit_key_point, local_contrast_norm, compute_feature_map)
@@ -393,9 +396,11 @@ def dictionary_learning_step(
     d_work = _native.unit_norm(d.detach().to(dev))  # :365 (a new tensor)
     residual = sig.clone()  # :367 -- the ORIGINAL signal, as in the reference
 
-    dense = compute_feature_map is not None or local_constrast_norm or isinstance(approx, slice) or (
+    dense = compute_feature_map is not None or isinstance(approx, slice) or (
         isinstance(approx, int) and not isinstance(approx, bool) and approx < n_samples)
-    if dense:
+    if local_constrast_norm and not dense:
+        atom, lag, gain, _ = _native.encode_lcn(sig, d_work, n_steps, want_residual=False)
+    elif dense:
         atom, lag, gain, _, _ = _sparse_code_dense(sig.view(batch, 1, n_samples), d_work, n_steps,
                                                    approx if not (approx is None) else None, None, None,
                                                    local_constrast_norm, compute_feature_map)

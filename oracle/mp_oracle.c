@@ -15,6 +15,7 @@
  *   scatter_segments (decode)  modules/matchingpursuit.py:20-58
  *   dictionary_learning_step   modules/matchingpursuit.py:348-419
  *   sparse_feature_map         modules/matchingpursuit.py:68-125
+ *   local contrast norm        modules/matchingpursuit.py:284-294  (mpo_encode_lcn)
  *
  * Arithmetic contract (this is what the HIP kernels are held to, bit for bit):
  *   - fm[a,t] is ONE fp32 fused-multiply-add chain in ascending k:
@@ -200,6 +201,66 @@ int mpo_encode(const float *signal, int64_t B, int64_t N, const float *du, int64
         if (residual) memcpy(residual + b * N, rp, (size_t)N * sizeof(float));
     }
     free(rp);
+    return 0;
+}
+
+/*
+ * sparse_code(..., local_contrast_norm=True) (modules/matchingpursuit.py:284-294): the step's event is the
+ * argmax of  fm - avg_pool2d(fm, 9x9, stride 1, pad 4)  over the (A, N) map (zero padding, every window
+ * divided by 81: count_include_pad), and its gain is the RAW map value there (:294).
+ *   avg[a,t] = (sum over a' = a-4..a+4 ascending, t' = t-4..t+4 ascending of fm[a',t'], ONE sequential
+ *              fp32 sum, cells outside the map skipped) / 81.0f     -- ATen's cpu_avg_pool2d loop order
+ *   lcn[a,t] = fm[a,t] - avg[a,t]        (fp32)
+ * Same outputs as mpo_encode (no top2).
+ */
+int mpo_encode_lcn(const float *signal, int64_t B, int64_t N, const float *du, int64_t A, int64_t L,
+                   int K, int64_t *atom, int64_t *lag, float *gain, float *residual) {
+    if (B < 0 || N <= 0 || A <= 0 || L <= 0 || K < 0) return -2;
+    float *rp = (float *)calloc((size_t)(N + L + MPO_TBLK), sizeof(float));
+    float *fm = (float *)malloc((size_t)A * N * sizeof(float));
+    if (!rp || !fm) { free(rp); free(fm); return -1; }
+    for (int64_t b = 0; b < B; ++b) {
+        memcpy(rp, signal + b * N, (size_t)N * sizeof(float));
+        for (int k = 0; k < K; ++k) {
+            best_t raw;
+            correlate_argmax(rp, N, du, A, L, fm, &raw);
+            best_t g = {-INFINITY, INT64_MAX, -INFINITY};
+#pragma omp parallel
+            {
+                best_t loc = {-INFINITY, INT64_MAX, -INFINITY};
+#pragma omp for schedule(static) nowait
+                for (int64_t a = 0; a < A; ++a) {
+                    int64_t a0 = a - 4 < 0 ? 0 : a - 4, a1 = a + 5 > A ? A : a + 5;
+                    for (int64_t t = 0; t < N; ++t) {
+                        int64_t t0 = t - 4 < 0 ? 0 : t - 4, t1 = t + 5 > N ? N : t + 5;
+                        float sum = 0.0f;
+                        for (int64_t ia = a0; ia < a1; ++ia)
+                            for (int64_t it = t0; it < t1; ++it) sum += fm[ia * N + it];
+                        float v = fm[a * N + t] - sum / 81.0f;
+                        best_update(&loc, v + 0.0f, a * N + t);
+                    }
+                }
+#pragma omp critical
+                {
+                    if (loc.v > g.v || (loc.v == g.v && loc.idx < g.idx)) g = loc;
+                }
+            }
+            int64_t ai = g.idx / N, p = g.idx % N;
+            float val = fm[g.idx]; /* torch.gather(fm, index=mx) :294 */
+            atom[b * K + k] = ai;
+            lag[b * K + k] = p;
+            gain[b * K + k] = val;
+            int64_t len = N - p < L ? N - p : L;
+            const float *da = du + ai * L;
+            for (int64_t i = 0; i < len; ++i) {
+                float at = da[i] * val;
+                rp[p + i] = rp[p + i] - at;
+            }
+        }
+        if (residual) memcpy(residual + b * N, rp, (size_t)N * sizeof(float));
+    }
+    free(rp);
+    free(fm);
     return 0;
 }
 

@@ -114,6 +114,25 @@ def encode(signal, dict_unit, n_steps):
     return dict(atom=atom, lag=lag, gain=gain, residual=residual, top2=top2)
 
 
+def encode_lcn(signal, dict_unit, n_steps):
+    """sparse_code(local_contrast_norm=True), matchingpursuit.py:284-294 -> dict(atom, lag, gain, residual)."""
+    s, sp = _f(signal)
+    du, dup = _f(dict_unit)
+    B, N = s.shape
+    A, L = du.shape
+    K = int(n_steps)
+    atom = np.zeros((B, K), dtype=np.int64)
+    lag = np.zeros((B, K), dtype=np.int64)
+    gain = np.zeros((B, K), dtype=np.float32)
+    residual = np.zeros((B, N), dtype=np.float32)
+    rc = lib().mpo_encode_lcn(sp, _i64(B), _i64(N), dup, _i64(A), _i64(L), ctypes.c_int(K),
+                              atom.ctypes.data_as(_ip), lag.ctypes.data_as(_ip),
+                              gain.ctypes.data_as(_fp), residual.ctypes.data_as(_fp))
+    if rc != 0:
+        raise RuntimeError(f"mpo_encode_lcn failed rc={rc}")
+    return dict(atom=atom, lag=lag, gain=gain, residual=residual)
+
+
 def scatter(atom, batch, lag, gain, dict_unit, B, N):
     a, ap = _i(np.ravel(atom))
     b, bp = _i(np.ravel(batch))

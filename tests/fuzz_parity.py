@@ -58,6 +58,13 @@ for case in range(n_cases):
         if not ok:
             bad += 1
             print(f"MISMATCH case {case} {name}: A{A} L{L} N{N} B{B} K{K} min top-2 gap {gap.min():.2e}", flush=True)
+    if A * N <= 400000:  # the local-contrast-norm rule (mp_encode_lcn_f32; the oracle's box filter is a plain loop)
+        wl = mp_oracle.encode_lcn(x, du, K)
+        a, l, g, r = [t.cpu().numpy() for t in nat.encode_lcn(xd, dud, K)]
+        if not (np.array_equal(a, wl["atom"]) and np.array_equal(l, wl["lag"]) and np.array_equal(g, wl["gain"]) and
+                np.array_equal(r, wl["residual"])):
+            bad += 1
+            print(f"MISMATCH case {case} lcn: A{A} L{L} N{N} B{B} K{K}", flush=True)
     if case % 10 == 9:
         print(f"{case + 1} cases done, {bad} mismatches", flush=True)
 # the convolution model of mp.py (raw atoms, v^2 update, no oracle): its three schedules must agree with each other

@@ -309,10 +309,70 @@ def main():
                         flat_amp=np.array([float(e[3]) for e in flat], dtype=np.float32),
                         recon=rec.numpy(), recon2=rec2.numpy(), **out)
 
+    lcn_fixtures(mp, norm)
+
     print("fixture report (name, min relative top-2 gap, residual dB, direct==fft picks):")
     for r in report:
         print("  ", r)
 
 
+LCN_CASES = [
+    # name, A, L, N, B, K, n_events, seed      (local_contrast_norm=True, :284-294)
+    ("lcn_24x100_n1000_b2_k10", 24, 100, 1000, 2, 10, 8, 707),
+    ("lcn_64x128_n4096_b3_k12", 64, 128, 4096, 3, 12, 12, 808),
+    ("lcn_7x33_n300_b2_k6", 7, 33, 300, 2, 6, 4, 909),   # fewer atoms than the 9-row box
+]
+
+
+def run_encode_lcn(mp, signal, d, n_steps):
+    """Reference sparse_code(local_contrast_norm=True) in selection order; also records the top two values
+    of the contrast-normalised map (recomputed in the hook exactly as :286-288 form it)."""
+    import torch.nn.functional as F
+    B, _, N = signal.shape
+    rec = {"atom": [], "lag": [], "gain": [], "top2": []}
+
+    def visit(fm, ai, p, a):
+        A_ = fm.shape[0]
+        m = fm.view(1, 1, A_, N)
+        lcn = (m - F.avg_pool2d(m, (9, 9), (1, 1), (4, 4))).reshape(-1)
+        rec["atom"].append(int(ai))
+        rec["lag"].append(int(p))
+        rec["gain"].append(float(fm[ai, int(p)]))
+        rec["top2"].append(torch.topk(lcn, 2).values.numpy().copy())
+
+    with torch.no_grad():
+        events, scatter, residual = mp.sparse_code(
+            signal, d, n_steps=n_steps, flatten=True, return_residual=True,
+            visit_key_point=visit, local_contrast_norm=True)
+    K = n_steps
+    return dict(atom=np.array(rec["atom"], dtype=np.int64).reshape(K, B).T.copy(),
+                lag=np.array(rec["lag"], dtype=np.int64).reshape(K, B).T.copy(),
+                gain=np.array(rec["gain"], dtype=np.float32).reshape(K, B).T.copy(),
+                top2=np.array(rec["top2"], dtype=np.float32).reshape(K, B, 2).transpose(1, 0, 2).copy(),
+                residual=residual.numpy()[:, 0, :].copy())
+
+
+def lcn_fixtures(mp, norm):
+    for name, A, L, N, B, K, n_ev, seed in LCN_CASES:
+        d = synth.make_dictionary(A, L, seed=seed)
+        x = synth.make_segments(B, N, d, n_events=n_ev, seed=seed)
+        dt = torch.from_numpy(d)
+        out = run_encode_lcn(mp, torch.from_numpy(x)[:, None, :], dt, K)
+        with torch.no_grad():
+            d_new = mp.dictionary_learning_step(torch.from_numpy(x)[:, None, :], torch.from_numpy(d.copy()),
+                                                n_steps=K, local_constrast_norm=True)
+        gap = (out["top2"][..., 0] - out["top2"][..., 1]) / np.abs(out["top2"][..., 0])
+        np.savez_compressed(os.path.join(HERE, f"encode_{name}.npz"), signal=x, d_raw=d,
+                            d_unit=norm.unit_norm(dt).numpy().astype(np.float32), d_new=d_new.numpy(),
+                            seed=np.int64(seed), **out)
+        print("  lcn", name, "min relative top-2 gap of the normalised map", float(gap.min()))
+
+
 if __name__ == "__main__":
-    main()
+    if len(sys.argv) > 1 and sys.argv[1] == "lcn":  # only the local-contrast-norm fixtures
+        torch.manual_seed(0)
+        torch.set_num_threads(8)
+        _mp, _conv, _norm, _stft, _ns = load_reference()
+        lcn_fixtures(_mp, _norm)
+    else:
+        main()

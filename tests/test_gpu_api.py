@@ -121,6 +121,27 @@ def test_local_contrast_norm_runs_and_differs_only_in_selection_rule():
     assert (recon + res - x).abs().max().item() < 1e-5  # still an exact decomposition
 
 
+@pytest.mark.parametrize("name", ["encode_lcn_24x100_n1000_b2_k10", "encode_lcn_7x33_n300_b2_k6"])
+def test_local_contrast_norm_api_matches_reference(golden_dir, name):
+    """sparse_code / dictionary_learning_step with the local-contrast-norm rule, against the real reference;
+    the hook-serving dense loop (torch box filter on the device) must agree with the native kernel."""
+    z = np.load(os.path.join(golden_dir, name + ".npz"))
+    d = torch.from_numpy(z["d_raw"]).to(DEV)
+    x = torch.from_numpy(z["signal"]).to(DEV)[:, None, :]
+    K = z["atom"].shape[1]
+    seen = []
+    ev, _, res = mp.sparse_code(x, d, n_steps=K, flatten=True, return_residual=True, local_contrast_norm=True)
+    mp.sparse_code(x, d, n_steps=K, flatten=True, local_contrast_norm=True,
+                   visit_key_point=lambda fm, ai, p, a: seen.append((ai, int(p))))
+    want = sorted((int(z["atom"][b, k]), b, int(z["lag"][b, k])) for b in range(x.shape[0]) for k in range(K))
+    assert sorted((e[0], e[1], int(e[2])) for e in ev) == want
+    B = x.shape[0]
+    assert seen == [(int(z["atom"][b, k]), int(z["lag"][b, k])) for k in range(K) for b in range(B)]
+    assert np.abs(res.cpu().numpy()[:, 0, :] - z["residual"]).max() <= 1e-5 * np.abs(z["signal"]).max()
+    d_new = mp.dictionary_learning_step(x, d, n_steps=K, local_constrast_norm=True)
+    assert np.abs(d_new.cpu().numpy() - z["d_new"]).max() <= 1e-5
+
+
 @pytest.mark.parametrize("name", ["dl_32x64_n2048_b4_k10", "dl_16x256_n8192_b2_k8"])
 def test_dictionary_learning_step_matches_reference(golden_dir, oracle, name):
     z = np.load(os.path.join(golden_dir, name + ".npz"))

@@ -129,6 +129,48 @@ def test_encode_matches_reference_golden(golden_dir, name):
     assert np.abs(rdb - z["residual_db"]).max() <= 1e-3
 
 
+LCN_GOLDEN = ["encode_lcn_24x100_n1000_b2_k10", "encode_lcn_64x128_n4096_b3_k12", "encode_lcn_7x33_n300_b2_k6"]
+
+
+@pytest.mark.parametrize("name", LCN_GOLDEN)
+def test_local_contrast_norm_matches_reference_golden(oracle, golden_dir, name):
+    """mp_encode_lcn_f32 against the real reference's sparse_code(local_contrast_norm=True) (:284-294)."""
+    z = np.load(os.path.join(golden_dir, name + ".npz"))
+    K = z["atom"].shape[1]
+    du = nat.unit_norm(torch.from_numpy(z["d_raw"]).to(DEV))
+    atom, lag, gain, residual = [t.cpu().numpy() for t in
+                                 nat.encode_lcn(torch.from_numpy(z["signal"]).to(DEV), du, K)]
+    assert np.array_equal(atom, z["atom"]) and np.array_equal(lag, z["lag"])
+    assert np.abs(gain - z["gain"]).max() <= REL * np.abs(z["gain"]).max()
+    assert np.abs(residual - z["residual"]).max() <= REL * np.abs(z["signal"]).max()
+    want = oracle.encode_lcn(z["signal"], du.cpu().numpy(), K)
+    assert np.array_equal(gain, want["gain"]) and np.array_equal(residual, want["residual"])
+
+
+@pytest.mark.parametrize("shape", ["ragged", "mid", "tiny", "atom_longer_than_segment", "k_chunks", "many_atoms",
+                                   "split_batch"])
+def test_local_contrast_norm_bitwise_vs_oracle(oracle, shape):
+    d, x, K = _inputs(shape)
+    du = oracle.unit_norm(d)
+    want = oracle.encode_lcn(x, du, K)
+    atom, lag, gain, residual = [t.cpu().numpy() for t in
+                                 nat.encode_lcn(torch.from_numpy(x).to(DEV), torch.from_numpy(du).to(DEV), K)]
+    assert np.array_equal(atom, want["atom"]) and np.array_equal(lag, want["lag"])
+    assert np.array_equal(gain, want["gain"]) and np.array_equal(residual, want["residual"])
+
+
+def test_local_contrast_norm_chunks_a_batch_whose_map_is_too_large(oracle, monkeypatch):
+    d, x, K = _inputs("split_batch")
+    du = oracle.unit_norm(d)
+    A, N = du.shape[0], x.shape[1]
+    monkeypatch.setattr(nat, "LCN_MAP_BYTES", 4 * A * N * 4)  # four segments per call: 9 -> 4 + 4 + 1
+    want = oracle.encode_lcn(x, du, K)
+    atom, lag, gain, residual = [t.cpu().numpy() for t in
+                                 nat.encode_lcn(torch.from_numpy(x).to(DEV), torch.from_numpy(du).to(DEV), K)]
+    assert np.array_equal(atom, want["atom"]) and np.array_equal(lag, want["lag"])
+    assert np.array_equal(residual, want["residual"])
+
+
 def test_scatter_decoder_vs_oracle_and_golden(oracle, golden_dir):
     z = np.load(os.path.join(golden_dir, "primitives.npz"))
     du = oracle.unit_norm(z["d_raw"])

@@ -55,6 +55,29 @@ def test_oracle_encode_matches_reference(oracle, golden_dir, name):
     assert np.abs(rec - z["recon"]).max() <= REL * max(1.0, np.abs(z["recon"]).max())
 
 
+LCN_GOLDEN = ["encode_lcn_24x100_n1000_b2_k10", "encode_lcn_64x128_n4096_b3_k12", "encode_lcn_7x33_n300_b2_k6"]
+
+
+@pytest.mark.parametrize("name", LCN_GOLDEN)
+def test_oracle_local_contrast_norm_matches_reference(oracle, golden_dir, name):
+    """sparse_code(local_contrast_norm=True), matchingpursuit.py:284-294: the selection rule on the
+    contrast-normalised map, the gain from the raw map."""
+    z = np.load(os.path.join(golden_dir, name + ".npz"))
+    du = oracle.unit_norm(z["d_raw"])
+    assert np.abs(du - z["d_unit"]).max() <= 2e-7
+    K = z["atom"].shape[1]
+    out = oracle.encode_lcn(z["signal"], du, K)
+    gap = (z["top2"][..., 0] - z["top2"][..., 1]) / np.abs(z["top2"][..., 0])
+    assert gap.min() >= 1e-4, "fixture has a near-tie; regenerate with another seed"
+    assert np.array_equal(out["atom"], z["atom"]) and np.array_equal(out["lag"], z["lag"])
+    assert np.abs(out["gain"] - z["gain"]).max() <= REL * np.abs(z["gain"]).max()
+    assert np.abs(out["residual"] - z["residual"]).max() <= REL * np.abs(z["signal"]).max()
+    # the rule differs from the plain argmax somewhere in the fixture set (else the fixture proves nothing)
+    plain = oracle.encode(z["signal"], du, K)
+    if name == "encode_lcn_64x128_n4096_b3_k12":
+        assert not (np.array_equal(plain["atom"], out["atom"]) and np.array_equal(plain["lag"], out["lag"]))
+
+
 def test_oracle_feature_map_and_decode_primitives(oracle, golden_dir):
     z = np.load(os.path.join(golden_dir, "primitives.npz"))
     du = oracle.unit_norm(z["d_raw"])
