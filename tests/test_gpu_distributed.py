@@ -115,3 +115,13 @@ def test_two_rank_gradient_all_reduce_of_the_model():
     for r in range(2):
         assert np.abs(got[r] - want).max() <= 1e-6 * max(np.abs(want).max(), 1e-12)
     assert np.array_equal(got[0], got[1])
+
+
+def test_rccl_backend_initialises_and_runs_the_collectives_used():
+    """A world-size-1 `nccl` (= RCCL) group in a child process: the backend loads on this box and the three
+    collectives bench.py / dictionary_learning_step issue complete on device tensors."""
+    import subprocess
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()))
+    out = subprocess.run([sys.executable, os.path.join(REPO, "scripts", "rccl_single_rank_check.py")], env=env,
+                         capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and "rccl ok" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
