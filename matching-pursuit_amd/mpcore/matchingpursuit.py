@@ -595,15 +595,81 @@ def sparse_coding_loss(recon, target, d, n_steps=100, device=None, approx=None, 
     return F.binary_cross_entropy(r_map, t_map)
 
 
+class _FeatureMapFn(torch.autograd.Function):
+    """fm = mp_feature_map_f32(residual, d_unit) (matchingpursuit.py:275-277), differentiable in both arguments.
+    The adjoints of the correlation -- a linear convolution of the incoming gradient with the atoms, and the
+    correlation of the residual with it -- are tensor operations (fp64 FFTs: exact to fp32 rounding)."""
+
+    @staticmethod
+    def forward(ctx, residual, d_unit):
+        ctx.save_for_backward(residual, d_unit)
+        return _native.feature_map(residual, d_unit)
+
+    @staticmethod
+    def backward(ctx, g):
+        residual, d_unit = ctx.saved_tensors
+        n_samples, atom_size = residual.shape[1], d_unit.shape[1]
+        m = n_samples + atom_size
+        gs = torch.fft.rfft(g.double(), n=m)  # [B, A, F]
+        g_res = g_d = None
+        if ctx.needs_input_grad[0]:  # sum_a sum_k g[b, a, n - k] d[a, k]
+            ds = torch.fft.rfft(d_unit.double(), n=m)
+            g_res = torch.fft.irfft((gs * ds[None]).sum(1), n=m)[:, :n_samples].float()
+        if ctx.needs_input_grad[1]:  # sum_b sum_t g[b, a, t] r[b, t + k]
+            rs = torch.fft.rfft(residual.double(), n=m)
+            g_d = torch.fft.irfft((gs.conj() * rs[:, None]).sum(0), n=m)[:, :atom_size].float()
+        return g_res, g_d
+
+
+def _key_points_with_grad(signal, d, n_steps, dev):
+    """The autograd form of sparse_code_to_differentiable_key_points: the reference's graph (:169-224) rebuilt
+    around the native encoder's picks -- dense map per step through _FeatureMapFn, value = the map at the pick,
+    time through the straight-through softmax of soft_dirac over the per-lag maximum (:192), the residual window
+    and the residual update as differentiable gathers / scatters.  Gradients reach the signal and the RAW
+    dictionary (through unit_norm, :161), as e_2023_6_7's Encoder trains its dictionary."""
+    from .sparse import soft_dirac
+    batch, _, n_samples = signal.shape
+    n_atoms, atom_size = d.shape
+    half = atom_size // 2
+    x = signal.to(dev, torch.float32)[:, 0, :]
+    dd = d.to(dev, torch.float32)
+    d_unit = dd / (torch.norm(dd, dim=-1, keepdim=True) + 1e-8)  # normalization.py:4-6, differentiable
+    with torch.no_grad():
+        atom, lag, _, _ = _native.encode_checked(x.detach(), _native.unit_norm(dd.detach()), n_steps,
+                                                 want_residual=False)
+    j = torch.arange(atom_size, device=dev)
+    rows = torch.arange(batch, device=dev)
+    lin = torch.linspace(0, 1, n_samples, device=dev)
+    zero = torch.zeros((), device=dev)
+    r = x
+    vecs = []
+    for i in range(n_steps):
+        fm = _FeatureMapFn.apply(r, d_unit)  # [B, A, N]
+        a_i, p_i = atom[:, i], lag[:, i]
+        value = fm[rows, a_i, p_i]  # :176 (the maximum, at the native pick)
+        time = soft_dirac(fm.max(dim=1)[0]) @ lin  # :192
+        start = p_i - half
+        idx = start[:, None] + j[None, : 2 * half]
+        valid = (start[:, None] >= 0) & (idx < n_samples)
+        win = torch.where(valid, r.gather(1, idx.clamp(0, n_samples - 1)), zero)  # :199-203
+        pad = torch.zeros(batch, atom_size - 2 * half, device=dev)
+        vecs.append(torch.cat([value[:, None], time[:, None] * 100, win, pad], dim=1))  # :210-216
+        pos = p_i[:, None] + j[None, :]
+        upd = torch.where(pos < n_samples, d_unit[a_i] * value[:, None], zero)  # :181, cropped at N
+        r = r - torch.zeros_like(r).scatter_add(1, pos.clamp(max=n_samples - 1), upd)  # :223-224
+    vecs = torch.stack(vecs, 0).reshape(n_steps * batch, 2 + atom_size)
+    return vecs, torch.norm(r, dim=-1).view(batch, 1)
+
+
 def sparse_code_to_differentiable_key_points(signal, d, n_steps=100, device=None):
-    """Forward values of modules/matchingpursuit.py:149-227: per event the vector
+    """modules/matchingpursuit.py:149-227: per event the vector
     [value, 100 * time, residual window of `atom_size` samples centred on the event] (the reference
     squeezes that window into `n_atoms` slots, :215, so it needs n_atoms == atom_size), events in step-major,
     batch-minor order, plus the norm of the final residual.  `time` is the argmax of max_a fm over lags on
-    linspace(0, 1, N) -- the forward value of the reference's soft_dirac(...) @ linspace (:192); its
-    straight-through softmax gradient is not reproduced (no autograd through this function).
-    The picks come from the native encoder; the windows are cut from the residual of each step, which is
-    replayed from the events with window-sized tensor operations."""
+    linspace(0, 1, N) -- the forward value of the reference's soft_dirac(...) @ linspace (:192).
+    The picks come from the native encoder.  Without autograd the windows are cut from the residual of each
+    step, replayed from the events with window-sized tensor operations; when the signal or the dictionary
+    requires a gradient the reference's graph is rebuilt around the picks (_key_points_with_grad)."""
     signal = signal.view(signal.shape[0], 1, -1)
     batch, _, n_samples = signal.shape
     n_atoms, atom_size = d.shape
@@ -612,6 +678,9 @@ def sparse_code_to_differentiable_key_points(signal, d, n_steps=100, device=None
     half = atom_size // 2
     out_dev = signal.device
     dev = _compute_device(signal)
+    if torch.is_grad_enabled() and (signal.requires_grad or d.requires_grad):
+        vecs, rnorm = _key_points_with_grad(signal, d, n_steps, dev)
+        return vecs.to(out_dev), rnorm.to(out_dev)
     with torch.no_grad():
         x = signal.detach().to(dev, torch.float32)[:, 0, :]
         d_unit = _native.unit_norm(d.detach().to(dev))

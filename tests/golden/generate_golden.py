@@ -310,6 +310,7 @@ def main():
                         recon=rec.numpy(), recon2=rec2.numpy(), **out)
 
     lcn_fixtures(mp, norm)
+    key_point_gradients(mp)
 
     print("fixture report (name, min relative top-2 gap, residual dB, direct==fft picks):")
     for r in report:
@@ -368,8 +369,31 @@ def lcn_fixtures(mp, norm):
         print("  lcn", name, "min relative top-2 gap of the normalised map", float(gap.min()))
 
 
+def key_point_gradients(mp):
+    """Autograd of sparse_code_to_differentiable_key_points (:149-227) w.r.t. the raw dictionary and the signal,
+    for a fixed random linear read-out of the event vectors plus the residual norms."""
+    dk = synth.make_dictionary(32, 32, seed=1313)
+    xk = synth.make_segments(2, 512, dk, n_events=5, seed=1313)
+    w = np.random.default_rng(1414).standard_normal((8, 34)).astype(np.float32)
+    dt = torch.from_numpy(dk.copy()).requires_grad_(True)
+    xt = torch.from_numpy(xk.copy()).requires_grad_(True)
+    vecs, rnorm = mp.sparse_code_to_differentiable_key_points(xt, dt, n_steps=4)
+    loss = (vecs * torch.from_numpy(w)).sum() + rnorm.sum()
+    loss.backward()
+    np.savez_compressed(os.path.join(HERE, "key_points_grad.npz"), signal=xk, d_raw=dk, weights=w,
+                        vecs=vecs.detach().numpy(), residual_norm=rnorm.detach().numpy(),
+                        loss=np.float64(loss.item()), grad_d=dt.grad.numpy(), grad_signal=xt.grad.numpy(),
+                        n_steps=np.int64(4))
+    print("  key point gradients: |grad_d| max", float(dt.grad.abs().max()), "|grad_signal| max",
+          float(xt.grad.abs().max()))
+
+
 if __name__ == "__main__":
-    if len(sys.argv) > 1 and sys.argv[1] == "lcn":  # only the local-contrast-norm fixtures
+    if len(sys.argv) > 1 and sys.argv[1] == "kp":  # only the key-point gradient fixture
+        torch.manual_seed(0)
+        torch.set_num_threads(8)
+        key_point_gradients(load_reference()[0])
+    elif len(sys.argv) > 1 and sys.argv[1] == "lcn":  # only the local-contrast-norm fixtures
         torch.manual_seed(0)
         torch.set_num_threads(8)
         _mp, _conv, _norm, _stft, _ns = load_reference()

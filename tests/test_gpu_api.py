@@ -350,6 +350,21 @@ def test_key_points_match_reference(golden_dir):
         mp.sparse_code_to_differentiable_key_points(torch.zeros(1, 256, device=DEV), torch.rand(8, 16, device=DEV), 2)
 
 
+def test_key_point_gradients_match_reference(golden_dir):
+    """Autograd through sparse_code_to_differentiable_key_points (:149-227) w.r.t. the raw dictionary and the
+    signal, against the reference's own autograd for the same linear read-out (tests/golden/generate_golden.py)."""
+    z = np.load(os.path.join(golden_dir, "key_points_grad.npz"))
+    x = torch.from_numpy(z["signal"]).to(DEV).requires_grad_(True)
+    d = torch.from_numpy(z["d_raw"]).to(DEV).requires_grad_(True)
+    vecs, rnorm = mp.sparse_code_to_differentiable_key_points(x, d, n_steps=int(z["n_steps"]))
+    assert np.abs(vecs.detach().cpu().numpy() - z["vecs"]).max() <= 2e-5 * np.abs(z["vecs"]).max()
+    loss = (vecs * torch.from_numpy(z["weights"]).to(DEV)).sum() + rnorm.sum()
+    assert abs(loss.item() - float(z["loss"])) <= 1e-4 * abs(float(z["loss"]))
+    loss.backward()
+    assert np.abs(d.grad.cpu().numpy() - z["grad_d"]).max() <= 2e-4 * np.abs(z["grad_d"]).max()
+    assert np.abs(x.grad.cpu().numpy() - z["grad_signal"]).max() <= 2e-4 * np.abs(z["grad_signal"]).max()
+
+
 @pytest.mark.parametrize("order", ["sequential", "even_odd"])
 def test_streaming_encode_carries_the_residual(oracle, order):
     """Long audio in windows of one segment at a 50 % hop: every window is encoded on what
