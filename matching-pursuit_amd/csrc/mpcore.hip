@@ -956,8 +956,8 @@ Workspace carve(const Geom &g, int path, char *base) {
     if (path == MP_PATH_FFT) {
         FftGeom f;
         if (make_fft_geom(g, &f)) {
-            size_t o_tw = take((size_t)f.M * sizeof(cpx));
-            size_t o_ps = take((size_t)g.NAT * f.NPT * f.M * sizeof(cpx));
+            size_t o_tw = take((size_t)f.M * 2 * sizeof(cpx));  // (split transforms: half-size + full-size table)
+            size_t o_ps = take((size_t)g.NAT * f.NPT * f.M * (f.split ? 2 : 1) * sizeof(cpx));  // split: one table per half
             size_t o_xs = take((size_t)g.B * f.NW * f.M * sizeof(cpx));
             size_t o_wn = take((size_t)g.B * f.NW * sizeof(float));
             size_t o_ce = take((size_t)g.B * g.NBLK * g.NAT * sizeof(float));
@@ -1169,18 +1169,34 @@ float FFT_TAU = 2.0e-5f;
 int fft_setup(const Geom &g, const Workspace &w, const float *du, int flags, hipStream_t st) {
     FftGeom f;
     if (!make_fft_geom(g, &f))
-        return fail(MP_ERR_UNSUPPORTED, "MP_PATH_FFT: atoms longer than 5398 samples need MP_PATH_INCREMENTAL%s");
+        return fail(MP_ERR_UNSUPPORTED, "MP_PATH_FFT: atoms longer than 10859 samples need MP_PATH_INCREMENTAL%s");
     if (g.B > 65535) return fail(MP_ERR_ARG, "MP_PATH_FFT: batch > 65535 per call%s");
-    const size_t lds = (size_t)f.M * sizeof(cpx);
+    const size_t lds = (size_t)(f.split ? f.M / 2 : f.M) * sizeof(cpx);
     const int64_t n_cells = (int64_t)g.NBLK * g.NAT;
     const int npairs = g.NAT * f.NPT;
     int rc;
-    hipLaunchKernelGGL(fft_twiddle_kernel, dim3((f.M + 255) / 256), dim3(256), 0, st, w.tw, f.M);
-    HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemsetAsync(w.overflow, 0, (size_t)g.B * sizeof(int), st));
     HIP_TRY(hipMemsetAsync(w.ekeys, 0, (size_t)g.B * (MAXCONT + 1) * sizeof(u64), st));
     HIP_TRY(hipMemsetAsync(w.bsum, 0, (size_t)g.B * g.NBLK * 2 * sizeof(unsigned), st));
     HIP_TRY(hipMemsetAsync(w.keys, 0, (size_t)g.B * n_cells * sizeof(u64), st));
+    if (f.split) {  // long atoms: two half-size transforms per M-point transform (mpfft.inc)
+        constexpr int LH = SPLIT_LOGH;
+        const int H = f.M / 2;
+        hipLaunchKernelGGL(fft_twiddle_kernel, dim3((H + 255) / 256), dim3(256), 0, st, w.tw, H);
+        hipLaunchKernelGGL(fft_twiddle_kernel, dim3((f.M + 255) / 256), dim3(256), 0, st, w.tw + H, f.M);
+        HIP_TRY(hipGetLastError());
+        if ((rc = fft_lds_attr(fft_dict_split_kernel<LH>, lds))) return rc;
+        if ((rc = fft_lds_attr(fft_window_split_kernel<LH>, lds))) return rc;
+        if ((rc = fft_lds_attr(fft_correlate_split_kernel<LH>, lds))) return rc;
+        hipLaunchKernelGGL(fft_dict_split_kernel<LH>, dim3(npairs, 2), dim3(256), lds, st, du, g.A, g.L, w.tw, w.pspec);
+        HIP_TRY(hipGetLastError());
+        const size_t lds_ref_s = lds_bytes(g);
+        if (!(flags & MP_FLAG_NO_DMA)) { if ((rc = fft_lds_attr(fft_refine_kernel<true>, lds_ref_s))) return rc; }
+        else { if ((rc = fft_lds_attr(fft_refine_kernel<false>, lds_ref_s))) return rc; }
+        return MP_OK;
+    }
+    hipLaunchKernelGGL(fft_twiddle_kernel, dim3((f.M + 255) / 256), dim3(256), 0, st, w.tw, f.M);
+    HIP_TRY(hipGetLastError());
     MP_FFT_DISPATCH(f.logM, {
         if ((rc = fft_lds_attr(fft_dict_kernel<LG>, lds))) return rc;
         if ((rc = fft_lds_attr(fft_window_kernel<LG>, lds))) return rc;
@@ -1200,7 +1216,9 @@ int fft_iteration(const Geom &g, const Workspace &w, const float *du, int K, int
                   int64_t *out_lag, float *out_gain, const Rule &rule, hipStream_t st) {
     FftGeom f;
     if (!make_fft_geom(g, &f)) return fail(MP_ERR_UNSUPPORTED, "MP_PATH_FFT: atom too long%s");
-    const size_t lds = (size_t)f.M * sizeof(cpx);
+    // split transforms: the four-kernel form between screens (the window kernel makes the next spectrum)
+    if (f.split) flags = (flags | MP_FLAG_FFT_UNFUSED) & ~(MP_FLAG_FFT_FUSED | MP_FLAG_FFT_QUARTER);
+    const size_t lds = (size_t)(f.split ? f.M / 2 : f.M) * sizeof(cpx);
     const int64_t n_cells = (int64_t)g.NBLK * g.NAT;
     const bool dma = !(flags & MP_FLAG_NO_DMA);
     const size_t lds_ref = lds_bytes(g);
@@ -1233,7 +1251,10 @@ int fft_iteration(const Geom &g, const Workspace &w, const float *du, int K, int
         const int *dirty = k == 0 ? nullptr : w.dirty;
         const int nw = k == 0 ? f.NW : 1;
         g_prof.begin(PROF_SELECT, st);
-        if (k == 0 || !fused_tail) {
+        if (f.split) {
+            hipLaunchKernelGGL(fft_window_split_kernel<SPLIT_LOGH>, dim3(nw, (unsigned)g.B, 2), dim3(256), lds, st, w.res,
+                               g.Ns, dirty, w.tw, w.xspec, w.wnorm, f.V, f.NW, (const float *)w.dscale);
+        } else if (k == 0 || !fused_tail) {
             MP_FFT_DISPATCH(f.logM, {
                 hipLaunchKernelGGL(fft_window_kernel<LG>, dim3(nw, (unsigned)g.B), dim3(256), lds, st, w.res, g.Ns,
                                    dirty, w.tw, w.xspec, w.wnorm, f.V, f.NW,
@@ -1242,6 +1263,25 @@ int fft_iteration(const Geom &g, const Workspace &w, const float *du, int K, int
         }
         g_prof.end(st);
         g_prof.begin(k == 0 ? PROF_CORR_FULL : PROF_CORR_INC, st);
+        if (f.split && !(flags & MP_FLAG_FFT_SIMPLE)) {
+            using C = ScreenCfg<SPLIT_LOGH>;
+            int pps = 16 / C::SLOTS;
+            const int64_t tasks = (int64_t)nw * g.NAT * g.B * 2;
+            while (pps > 1 && tasks * (16 / (C::SLOTS * pps)) < 8 * (int64_t)num_cus()) pps >>= 1;
+            if (screen_pps_override > 0 && 16 % (C::SLOTS * screen_pps_override) == 0) pps = screen_pps_override;
+            const size_t lds_s = ((size_t)C::SLOTS * C::M + C::M / 64 + 64) * sizeof(cpx);
+            const bool seg_fast = (size_t)g.NAT * f.NPT * f.M * 2 * sizeof(cpx) > (size_t)16 << 20;
+            const unsigned gwp = 2 * nw * (16 / (C::SLOTS * pps));
+            const dim3 grid = seg_fast ? dim3((unsigned)g.B, gwp, g.NAT) : dim3(gwp, g.NAT, (unsigned)g.B);
+            if ((rc = fft_lds_attr(fft_screen_split_kernel<SPLIT_LOGH>, lds_s))) return rc;
+            hipLaunchKernelGGL(fft_screen_split_kernel<SPLIT_LOGH>, grid, dim3(C::WG), lds_s, st, w.xspec, w.pspec,
+                               w.tw, dirty, w.wnorm, w.keys, w.ceps, g.N, g.A, g.NBLK, g.NAT, f.V, f.NW, FFT_TAU, pps,
+                               (int)seg_fast, (float *)nullptr, (unsigned *)nullptr);
+        } else if (f.split) {
+            hipLaunchKernelGGL(fft_correlate_split_kernel<SPLIT_LOGH>, dim3(2 * nw, g.NAT, (unsigned)g.B), dim3(256), lds, st,
+                               w.xspec, w.pspec, w.tw, dirty, w.wnorm, w.keys, w.ceps, g.N, g.A, g.NBLK, g.NAT, f.V,
+                               f.NW, FFT_TAU);
+        } else
         MP_FFT_DISPATCH(f.logM, {
             if (LG >= 10 && !(flags & MP_FLAG_FFT_SIMPLE)) {
                 constexpr int LS = LG >= 10 ? LG : 10;  // (the branch is dead for smaller LG)

@@ -7,7 +7,7 @@ REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(REPO, "matching-pursuit_amd"))
 from mpcore import _native as nat
 from mpcore import synth
-for (A, L, N, M) in ((512, 512, 32768, 2048), (256, 2048, 32768, 8192)):
+for (A, L, N, M) in ((512, 512, 32768, 2048), (256, 2048, 32768, 8192), (64, 8192, 98304, 32768)):
     d = synth.make_dictionary(A, L, seed=1000)
     x = torch.from_numpy(synth.make_segments(4, N, d, n_events=192, seed=1002)).cuda()
     du = nat.unit_norm(torch.from_numpy(d).cuda())

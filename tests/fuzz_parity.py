@@ -28,6 +28,8 @@ for case in range(n_cases):
         A = int(rng.integers(2, 20)); L = int(rng.choice([8, 32])); N = int(rng.integers(100, 600)); B = 3; K = 40
     if case % 10 == 3:   # more than 16384 cells per segment: the block-summary select (short atoms) / the four-kernel form
         A = int(rng.choice([1000, 1024, 1500])); L = int(rng.choice([32, 64, 600])); N = int(rng.integers(36000, 48000)); B = 2; K = 3
+    if case % 10 == 4:   # atoms beyond 5398 samples: split transforms (two 2^14-point halves per 2^15-point transform)
+        A = int(rng.integers(1, 10)); L = int(rng.choice([5399, 8192, 10859])); N = int(rng.integers(L // 2, 30000)); B = int(rng.choice([1, 2, 9])); K = 3
     d = synth.make_dictionary(A, L, seed=1000 + case)
     x = synth.make_segments(B, N, d, n_events=min(3 * K, 12), seed=5000 + case) if N > L else \
         rng.standard_normal((B, N)).astype(np.float32)

@@ -52,6 +52,8 @@ SHAPES = {
     "k_chunks": (40, 1100, 3000, 2, 6, 4, 16),   # L > 512: several LDS chunks per correlation
     "many_atoms": (200, 32, 700, 1, 10, 6, 17),  # A not a multiple of the 64-atom tile
     "split_batch": (20, 48, 900, 9, 6, 5, 18),   # B >= 8: two sub-batches on forked streams, 4 + 5 segments
+    "long_atoms": (6, 6000, 9000, 2, 5, 3, 19),  # L > 5398: 2^15-point transforms as two 2^14-point halves
+    "long_atoms_two_windows": (5, 7000, 30000, 2, 4, 3, 20),  # ... and a full pass of two windows; odd atom count
 }
 
 
@@ -401,3 +403,24 @@ def test_fft_screen_survives_extreme_amplitudes(oracle, scale):
         assert keep.all()
         assert np.array_equal(atom, want["atom"]) and np.array_equal(lag, want["lag"])
         assert np.array_equal(gain, want["gain"]) and np.array_equal(res, want["residual"])
+
+
+@pytest.mark.parametrize("scale", [1.0, 1e-30, 1e18])
+def test_long_atom_split_transforms_planted_events_and_extreme_amplitudes(oracle, scale):
+    """Atoms beyond 5398 samples (the multiband model's largest band has 8192): every 2^15-point transform of the
+    FFT schedule runs as two 2^14-point halves.  Both screens (register transform, plain radix-4), scaled
+    dictionaries and extreme amplitudes, against the oracle bit for bit; the convolution model's schedules
+    must agree with each other too."""
+    du = oracle.unit_norm(synth.make_dictionary(9, 8192, seed=31))
+    x = (synth.make_segments(3, 20000, du, n_events=6, seed=32) * scale).astype(np.float32)
+    want = oracle.encode(x, du, 5)
+    for flags in (0, nat.MP_FLAG_FFT_SIMPLE, nat.MP_FLAG_REFINE_MFMA, nat.MP_FLAG_NO_OVERLAP):
+        atom, lag, gain, res = _gpu_encode(x, du, 5, nat.MP_PATH_FFT, flags)
+        assert not np.isnan(gain).any()
+        assert np.array_equal(atom, want["atom"]) and np.array_equal(lag, want["lag"])
+        assert np.array_equal(gain, want["gain"]) and np.array_equal(res, want["residual"])
+    if scale == 1.0:
+        xd, dd = torch.from_numpy(x).to(DEV), torch.from_numpy(du * 1.7).to(DEV)
+        ref = nat.encode(xd, dd, 4, path=nat.MP_PATH_INCREMENTAL, conv_model=True)
+        out = nat.encode(xd, dd, 4, path=nat.MP_PATH_FFT, conv_model=True)
+        assert all(torch.equal(a, b) for a, b in zip(out, ref))
