@@ -957,7 +957,7 @@ Workspace carve(const Geom &g, int path, char *base) {
         FftGeom f;
         if (make_fft_geom(g, &f)) {
             size_t o_tw = take((size_t)f.M * 2 * sizeof(cpx));  // (split transforms: half-size + full-size table)
-            size_t o_ps = take((size_t)g.NAT * f.NPT * f.M * (f.split ? 2 : 1) * sizeof(cpx));  // split: one table per half
+            size_t o_ps = take((size_t)g.NAT * f.NPT * f.M * sizeof(cpx));
             size_t o_xs = take((size_t)g.B * f.NW * f.M * sizeof(cpx));
             size_t o_wn = take((size_t)g.B * f.NW * sizeof(float));
             size_t o_ce = take((size_t)g.B * g.NBLK * g.NAT * sizeof(float));
@@ -1266,12 +1266,12 @@ int fft_iteration(const Geom &g, const Workspace &w, const float *du, int K, int
         if (f.split && !(flags & MP_FLAG_FFT_SIMPLE)) {
             using C = ScreenCfg<SPLIT_LOGH>;
             int pps = 16 / C::SLOTS;
-            const int64_t tasks = (int64_t)nw * g.NAT * g.B * 2;
+            const int64_t tasks = (int64_t)nw * g.NAT * g.B;
             while (pps > 1 && tasks * (16 / (C::SLOTS * pps)) < 8 * (int64_t)num_cus()) pps >>= 1;
             if (screen_pps_override > 0 && 16 % (C::SLOTS * screen_pps_override) == 0) pps = screen_pps_override;
             const size_t lds_s = ((size_t)C::SLOTS * C::M + C::M / 64 + 64) * sizeof(cpx);
-            const bool seg_fast = (size_t)g.NAT * f.NPT * f.M * 2 * sizeof(cpx) > (size_t)16 << 20;
-            const unsigned gwp = 2 * nw * (16 / (C::SLOTS * pps));
+            const bool seg_fast = (size_t)g.NAT * f.NPT * f.M * sizeof(cpx) > (size_t)16 << 20;
+            const unsigned gwp = nw * (16 / (C::SLOTS * pps));
             const dim3 grid = seg_fast ? dim3((unsigned)g.B, gwp, g.NAT) : dim3(gwp, g.NAT, (unsigned)g.B);
             if ((rc = fft_lds_attr(fft_screen_split_kernel<SPLIT_LOGH>, lds_s))) return rc;
             hipLaunchKernelGGL(fft_screen_split_kernel<SPLIT_LOGH>, grid, dim3(C::WG), lds_s, st, w.xspec, w.pspec,

@@ -226,8 +226,11 @@ def test_bad_arguments_fail_loudly():
         nat.encode(torch.zeros(1, 64), du, 1)  # CPU tensor
     with pytest.raises(nat.NativeError):
         nat.encode(torch.zeros(1, 64, device=DEV), du, 1, path=77)
-    with pytest.raises(nat.NativeError):  # one transform must fit LDS: atoms > 5398 samples
-        nat.encode(torch.zeros(1, 8000, device=DEV), torch.rand(2, 6000, device=DEV), 1, path=nat.MP_PATH_FFT)
+    with pytest.raises(nat.NativeError):  # a transform must fit LDS whole or as two halves: atoms > 10859 samples
+        nat.encode(torch.zeros(1, 16000, device=DEV), torch.rand(2, 11000, device=DEV), 1, path=nat.MP_PATH_FFT)
+    # ... and the default schedule falls back to the incremental one for those
+    a, l, g, r = nat.encode_checked(torch.rand(1, 16000, device=DEV), nat.unit_norm(torch.rand(2, 11000, device=DEV)), 1)
+    assert a.shape == (1, 1) and not torch.isnan(g).any()
 
 
 @pytest.mark.parametrize("log2_m", [8, 9, 10, 11, 12, 13, 14])
