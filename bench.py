@@ -159,7 +159,7 @@ def roofline_fft(prof, n_segments, steps):
     out = {
         "bound": "hbm", "achieved": round(achieved, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
         "frac": round(achieved / PEAK_HBM_GBS, 4), "traffic": pmc_traffic("fft_screen"),
-        "kernel": "fft_screen_kernel<11,false> (radix-16 Stockham, packed fp32)",
+        "kernel": "fft_screen_kernel<11> (radix-16 Stockham, packed fp32)",
     }
     out.update(per_kind)
     out.update({
