@@ -312,6 +312,31 @@ def test_c2_roundtrip_and_monotone_energy(c2_inputs):
     assert (gain[:, 0:1] >= gain - 1e-6).all()
 
 
+def test_c2_local_contrast_norm_roundtrip_and_box_filter_cross_check(c2_inputs):
+    """The local-contrast-norm schedule at the headline shape (too large for the oracle's plain loops): the
+    size-independent properties -- decode(events) + residual == signal, every step removes its gain^2 of energy,
+    the gain IS the raw feature-map value at the pick -- and, on two segments, the picks of an independent
+    implementation of the rule (mp_feature_map_f32 + torch's avg_pool2d / argmax on the device)."""
+    from mpcore import matchingpursuit as mpm
+    d, x = c2_inputs
+    du = nat.unit_norm(d)
+    K = 24
+    atom, lag, gain, residual = nat.encode_lcn(x, du, K)
+    B, N = x.shape
+    recon = torch.zeros_like(x)
+    batch = torch.arange(B, device=DEV)[:, None].expand(B, K)
+    nat.scatter(atom, batch, lag, gain, du, recon)
+    assert (recon + residual - x).abs().max().item() <= REL * x.abs().max().item() * 4
+    e0, e1 = (x.double() ** 2).sum(-1), (residual.double() ** 2).sum(-1)
+    interior = lag + du.shape[1] <= N
+    removed = ((gain.double() ** 2) * interior).sum(-1)
+    assert (e1 < e0).all() and ((e0 - e1) >= 0.99 * removed).all()
+    fm0 = nat.feature_map(x[:2], du)  # step 0: the gain is the raw map at the pick (:294)
+    assert torch.equal(gain[:2, 0], fm0[torch.arange(2), atom[:2, 0], lag[:2, 0]])
+    a2, l2, g2, r2, _ = mpm._sparse_code_dense(x[:2, None, :], du, K, None, None, None, True, None)
+    assert torch.equal(a2, atom[:2]) and torch.equal(l2, lag[:2])
+
+
 def test_c4_shape_paths_agree_and_roundtrip():
     """BASELINE configs[3] shape (4096 x 2048 dictionary, 131072-sample segments), small batch:
     FFT screen+refine == direct fma-chain kernels bit for bit; decode(events) + residual == signal."""
