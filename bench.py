@@ -323,6 +323,21 @@ def main():
                     "ms_per_step": round(vdt / vsteps * 1e3, 4), "steps": vsteps,
                     "bit_identical_to_headline": bool(same), "roofline": vroof,
                 }
+            # the library default once more, replayed from a captured hipGraph (mpcore.EncodePlan)
+            plan = nat.EncodePlan(B_PER_GPU, N, du, K_ITERS, path=nat.MP_PATH_FFT)
+            plan(x)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(args.steps):
+                pout = plan(x)
+            torch.cuda.synchronize()
+            pdt = time.perf_counter() - t0
+            line["variants"]["fft_library_default_hipgraph_replay"] = {
+                "value": round(B_PER_GPU * K_ITERS * args.steps / pdt, 2), "unit": "segment-iterations/s",
+                "ms_per_step": round(pdt / args.steps * 1e3, 4), "steps": args.steps,
+                "bit_identical_to_headline": bool(all(torch.equal(p, q) for p, q in zip(pout, out))),
+                "note": "includes the device copy of the batch into the plan's static input",
+            }
         if not args.no_cpu:
             base, parity = cpu_baseline(d, x_host, (atom, lag, gain))
             line["cpu_baseline"] = base

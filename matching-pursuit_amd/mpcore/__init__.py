@@ -1,6 +1,6 @@
 """mpcore -- MI355X-native greedy matching pursuit."""
 from . import _native  # noqa: F401
-from ._native import NativeError  # noqa: F401
+from ._native import EncodePlan, NativeError  # noqa: F401
 from .matchingpursuit import (  # noqa: F401
     build_scatter_segments, flatten_atom_dict, sparse_code, dictionary_learning_step,
     sparse_feature_map, sparse_coding_loss, SparseCodingLoss, unit_norm, torch_conv, fft_convolve,

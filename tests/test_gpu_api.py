@@ -399,3 +399,22 @@ def test_streaming_encode_carries_the_residual(oracle, order):
     with pytest.raises(ValueError):
         streaming.encode_streaming(torch.zeros(1, 100, device=DEV), torch.rand(4, 16, device=DEV), 64, 16, 2,
                                    order="even_odd")
+
+
+def test_encode_plan_replays_a_captured_graph(oracle):
+    """EncodePlan: the whole encode captured once as a hipGraph; every replay on new data gives what the plain
+    call gives, bit for bit (both the two-sub-batch FFT schedule with its forked streams and the MFMA one)."""
+    from mpcore import _native as nat
+    d = synth.make_dictionary(48, 64, seed=41)
+    du = nat.unit_norm(torch.from_numpy(d).to(DEV))
+    for B, path in ((70, None), (3, nat.MP_PATH_INCREMENTAL)):
+        plan = nat.EncodePlan(B, 2500, du, 7, path=path)
+        for seed in (42, 43):
+            x = torch.from_numpy(synth.make_segments(B, 2500, d, n_events=9, seed=seed)).to(DEV)
+            got = [t.clone() for t in plan(x)]
+            want = nat.encode(x, du, 7, path=plan.path)
+            assert all(torch.equal(a, b) for a, b in zip(got, want))
+        ref = oracle.encode(x.cpu().numpy(), du.cpu().numpy(), 7)
+        assert np.array_equal(got[0].cpu().numpy(), ref["atom"]) and np.array_equal(got[3].cpu().numpy(), ref["residual"])
+    with pytest.raises(nat.NativeError):
+        plan(torch.zeros(4, 2500, device=DEV))
