@@ -675,6 +675,65 @@ __global__ __launch_bounds__(256) void select_subtract_kernel(
 }
 
 // ------------------------------------------------------------------------------------------------
+// Backward pass of the gradient-trained model's analysis loop (mp.py:54-66; what autograd does to
+//   v_i = conv(r_i, atoms)[a_i, t_i],  b_i = v_i^2 * atom_{a_i} placed at t_i (cropped at N),  r_{i+1} = r_i - b_i,
+// channels[:, i] = b_i) in ONE launch: one workgroup per segment walks the K steps from the last to the first.
+// With G the gradient arriving at the channels and lam = d loss / d r_{i+1}:
+//   r_i    = r_{i+1} + b_i                                   (the residual, walked back from r_K)
+//   gw[j]  = G[i, t+j] - lam[t+j]                            (d loss / d b_i on the atom's support)
+//   dv     = 2 v sum_j gw[j] atom[j]                         (through b_i = v^2 atom)
+//   row[j] = v^2 gw[j] + dv r_i[t-j]                         (d loss / d atom_{a_i} from this event)
+//   lam[t-j] += dv atom[j]                                    (through v_i = sum_j r_i[t-j] atom[j])
+// The recurrence is sequential in i by construction; as ~17 tensor operations per step it was launch-bound
+// (4.4 ms of GPU time and 6.9 ms of host time per train step at the config-5 shape).  `rows` [B, K, L] are
+// summed into the dictionary gradient by the caller (one index_add); lam ends as d loss / d audio.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void conv_model_backward_kernel(
+    const float *__restrict__ atoms, int64_t L, const int64_t *__restrict__ a_idx, const int64_t *__restrict__ t_idx,
+    const float *__restrict__ val, int K, const float *__restrict__ res_final, const float *__restrict__ gch,
+    int64_t N, float *lam, float *rows, float *r) {
+    __shared__ float s_red[4];
+    const int64_t b = blockIdx.x;
+    const int tid = threadIdx.x;
+    float *rb = r + b * N, *lb = lam + b * N;
+    const float *gb = gch + b * K * N;
+    for (int64_t n = tid; n < N; n += 256) {
+        rb[n] = res_final[b * N + n];
+        lb[n] = 0.0f;
+    }
+    __syncthreads();
+    for (int i = K - 1; i >= 0; --i) {
+        const int64_t a = a_idx[b * K + i], t = t_idx[b * K + i];
+        const float v = val[b * K + i], v2 = v * v;
+        const float *d = atoms + a * L;
+        float *row = rows + (b * K + i) * L;
+        float part = 0.0f;
+        for (int64_t j = tid; j < L; j += 256) {
+            const int64_t pos = t + j;
+            float gw = 0.0f;
+            if (pos < N) {
+                rb[pos] = rb[pos] + v2 * d[j];
+                gw = gb[(int64_t)i * N + pos] - lb[pos];
+                part += gw * d[j];
+            }
+            row[j] = gw;  // parked until dv is known (lam[t] is about to change)
+        }
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) part += __shfl_xor(part, off, 64);
+        if ((tid & 63) == 0) s_red[tid >> 6] = part;
+        __syncthreads();  // r_i complete, every lam[t+j] read
+        const float dv = 2.0f * v * (s_red[0] + s_red[1] + s_red[2] + s_red[3]);
+        for (int64_t j = tid; j < L; j += 256) {
+            const int64_t back = t - j;
+            const float rw = back >= 0 ? rb[back] : 0.0f;
+            row[j] = v2 * row[j] + dv * rw;
+            if (back >= 0) lb[back] = lb[back] + dv * d[j];
+        }
+        __syncthreads();  // lam updated before the next step reads it; s_red free
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // Local contrast norm (modules/matchingpursuit.py:284-294): the step's event is the argmax of
 //   lcn[a,t] = fm[a,t] - avg_pool2d(fm, 9x9, stride 1, zero pad 4, count_include_pad)[a,t]
 // over the dense (A, N) map, and its gain is the RAW map value there (:294).  avg is ONE sequential fp32 sum
@@ -1775,6 +1834,20 @@ int mp_dictionary_update_f32(float *residual, float *sparse_zeroed, int64_t B, i
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(dictionary_update_kernel, dim3(1), dim3(1024), lds, static_cast<hipStream_t>(stream), residual,
                        sparse_zeroed, N, dict_work, L, order, offsets, n_groups, ev_batch, ev_lag, ev_rows, ev_norm, eps);
+    HIP_TRY(hipGetLastError());
+    return MP_OK;
+}
+
+int mp_conv_model_backward_f32(const float *atoms, int64_t A, int64_t L, const int64_t *atom_idx,
+                               const int64_t *time_idx, const float *value, int K, const float *residual_final,
+                               const float *grad_channels, int64_t B, int64_t N, float *grad_audio, float *grad_rows,
+                               float *scratch, void *stream) {
+    if (B == 0) return MP_OK;
+    if (!atoms || !atom_idx || !time_idx || !value || !residual_final || !grad_channels || !grad_audio || !grad_rows ||
+        !scratch || A <= 0 || L <= 0 || K < 0 || B < 0 || N <= 0)
+        return fail(MP_ERR_ARG, "mp_conv_model_backward_f32: bad arguments%s");
+    hipLaunchKernelGGL(conv_model_backward_kernel, dim3((unsigned)B), dim3(256), 0, static_cast<hipStream_t>(stream), atoms,
+                       L, atom_idx, time_idx, value, K, residual_final, grad_channels, N, grad_audio, grad_rows, scratch);
     HIP_TRY(hipGetLastError());
     return MP_OK;
 }

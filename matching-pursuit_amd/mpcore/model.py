@@ -52,6 +52,17 @@ class _ConvModelFn(torch.autograd.Function):
     def backward(ctx, grad_channels):
         atoms, a_idx, t_idx, v, r = ctx.saved_tensors
         B, N, A, L, K = ctx.shape
+        # the whole reverse walk in one launch (mp_conv_model_backward_f32), then one index_add over the events
+        lam, rows = _native.conv_model_backward(atoms, a_idx, t_idx, v, r, grad_channels)
+        g_atoms = torch.zeros_like(atoms).index_add_(0, a_idx.reshape(-1), rows.reshape(B * K, L))
+        return lam, g_atoms, None, None
+
+    @staticmethod
+    def backward_stepwise(ctx, grad_channels):
+        """The same walk as ~17 tensor operations per step: the statement of what the kernel computes, kept for
+        the tests (tests/test_gpu_api.py compares the two)."""
+        atoms, a_idx, t_idx, v, r = ctx.saved_tensors
+        B, N, A, L, K = ctx.shape
         dev = atoms.device
         j = torch.arange(L, device=dev)
         bidx = torch.arange(B, device=dev)[:, None]

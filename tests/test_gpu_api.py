@@ -418,3 +418,25 @@ def test_encode_plan_replays_a_captured_graph(oracle):
         assert np.array_equal(got[0].cpu().numpy(), ref["atom"]) and np.array_equal(got[3].cpu().numpy(), ref["residual"])
     with pytest.raises(nat.NativeError):
         plan(torch.zeros(4, 2500, device=DEV))
+
+
+def test_conv_model_backward_kernel_equals_the_stepwise_walk():
+    """mp_conv_model_backward_f32 against the same reverse walk written as tensor operations
+    (_ConvModelFn.backward_stepwise): atoms whose length is no multiple of the workgroup, events cropped at the
+    end of the segment and events near its start (windows reaching before sample 0)."""
+    from types import SimpleNamespace
+    from mpcore import _native as nat
+    from mpcore.model import _ConvModelFn
+    torch.manual_seed(3)
+    A, L, N, B, K = 9, 300, 1500, 3, 7
+    atoms = (torch.rand(A, L, device=DEV) - 0.5) * 0.2
+    x = torch.randn(B, N, device=DEV)
+    a_idx, t_idx, v, r = nat.encode(x, atoms, K, path=nat.MP_PATH_INCREMENTAL, conv_model=True)
+    t_idx = t_idx.clone()
+    t_idx[0, 0], t_idx[1, 1], t_idx[2, 2] = 3, N - 2, L // 2  # force edge positions (any events are valid inputs)
+    g = torch.randn(B, K, N, device=DEV)
+    ctx = SimpleNamespace(saved_tensors=(atoms, a_idx, t_idx, v, r), shape=(B, N, A, L, K))
+    lam_ref, g_ref, _, _ = _ConvModelFn.backward_stepwise(ctx, g)
+    lam, g_atoms, _, _ = _ConvModelFn.backward(ctx, g)
+    assert (lam - lam_ref).abs().max().item() <= 1e-5 * lam_ref.abs().max().item()
+    assert (g_atoms - g_ref).abs().max().item() <= 1e-5 * g_ref.abs().max().item()
