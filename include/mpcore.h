@@ -202,13 +202,15 @@ int mp_gather_sum_f32(const float *x, int64_t B, int64_t N, const int64_t *batch
  * Backward pass of mp_encode_conv_f32, i.e. of the analysis loop of the reference's gradient-trained model
  * (mp.py:54-66: what loss.backward() at mp.py:104 does to it), in one launch: given the events of the forward pass
  * (atom_idx, time_idx, value [B, K]), the residual it ended with [B, N] and the gradient arriving at the K event
- * channels [B, K, N], it returns grad_audio [B, N] and, per event, the row grad_rows [B, K, L] to be added to the
+ * channels [B, K, N] (windowed = 0) -- or only at each channel's own support, [B, K, L] with entry j of event i
+ * belonging to sample time_idx + j (windowed = 1: a loss that works on the events never forms the dense
+ * channels) -- it returns grad_audio [B, N] and, per event, the row grad_rows [B, K, L] to be added to the
  * gradient of atoms[atom_idx] (the caller sums rows of equal atoms: one index_add).  scratch: [B, N] floats.
  */
 int mp_conv_model_backward_f32(const float *atoms, int64_t A, int64_t L, const int64_t *atom_idx,
                                const int64_t *time_idx, const float *value, int K, const float *residual_final,
-                               const float *grad_channels, int64_t B, int64_t N, float *grad_audio, float *grad_rows,
-                               float *scratch, void *stream);
+                               const float *grad_channels, int windowed, int64_t B, int64_t N, float *grad_audio,
+                               float *grad_rows, float *scratch, void *stream);
 
 /*
  * The atom-by-atom update loop of dictionary_learning_step (modules/matchingpursuit.py:391-415) in one

@@ -691,12 +691,13 @@ __global__ __launch_bounds__(256) void select_subtract_kernel(
 __global__ __launch_bounds__(256) void conv_model_backward_kernel(
     const float *__restrict__ atoms, int64_t L, const int64_t *__restrict__ a_idx, const int64_t *__restrict__ t_idx,
     const float *__restrict__ val, int K, const float *__restrict__ res_final, const float *__restrict__ gch,
-    int64_t N, float *lam, float *rows, float *r) {
+    int64_t N, float *lam, float *rows, float *r, int windowed) {
     __shared__ float s_red[4];
     const int64_t b = blockIdx.x;
     const int tid = threadIdx.x;
     float *rb = r + b * N, *lb = lam + b * N;
-    const float *gb = gch + b * K * N;
+    // the gradient arriving at the channels: dense [B, K, N], or only each event's own support [B, K, L]
+    const float *gb = gch + b * K * (windowed ? L : N);
     for (int64_t n = tid; n < N; n += 256) {
         rb[n] = res_final[b * N + n];
         lb[n] = 0.0f;
@@ -713,7 +714,7 @@ __global__ __launch_bounds__(256) void conv_model_backward_kernel(
             float gw = 0.0f;
             if (pos < N) {
                 rb[pos] = rb[pos] + v2 * d[j];
-                gw = gb[(int64_t)i * N + pos] - lb[pos];
+                gw = (windowed ? gb[(int64_t)i * L + j] : gb[(int64_t)i * N + pos]) - lb[pos];
                 part += gw * d[j];
             }
             row[j] = gw;  // parked until dv is known (lam[t] is about to change)
@@ -1840,14 +1841,15 @@ int mp_dictionary_update_f32(float *residual, float *sparse_zeroed, int64_t B, i
 
 int mp_conv_model_backward_f32(const float *atoms, int64_t A, int64_t L, const int64_t *atom_idx,
                                const int64_t *time_idx, const float *value, int K, const float *residual_final,
-                               const float *grad_channels, int64_t B, int64_t N, float *grad_audio, float *grad_rows,
-                               float *scratch, void *stream) {
+                               const float *grad_channels, int windowed, int64_t B, int64_t N, float *grad_audio,
+                               float *grad_rows, float *scratch, void *stream) {
     if (B == 0) return MP_OK;
     if (!atoms || !atom_idx || !time_idx || !value || !residual_final || !grad_channels || !grad_audio || !grad_rows ||
         !scratch || A <= 0 || L <= 0 || K < 0 || B < 0 || N <= 0)
         return fail(MP_ERR_ARG, "mp_conv_model_backward_f32: bad arguments%s");
     hipLaunchKernelGGL(conv_model_backward_kernel, dim3((unsigned)B), dim3(256), 0, static_cast<hipStream_t>(stream), atoms,
-                       L, atom_idx, time_idx, value, K, residual_final, grad_channels, N, grad_audio, grad_rows, scratch);
+                       L, atom_idx, time_idx, value, K, residual_final, grad_channels, N, grad_audio, grad_rows, scratch,
+                       windowed);
     HIP_TRY(hipGetLastError());
     return MP_OK;
 }

@@ -62,7 +62,8 @@ def lib():
         L.mp_workspace_bytes.restype = ctypes.c_size_t
         L.mp_workspace_bytes.argtypes = [i64, i64, i64, i64, ctypes.c_int, ctypes.c_int]
         L.mp_unit_norm_f32.argtypes = [vp, i64, i64, fp, vp, vp]
-        L.mp_conv_model_backward_f32.argtypes = [vp, i64, i64, vp, vp, vp, ctypes.c_int, vp, vp, i64, i64, vp, vp, vp, vp]
+        L.mp_conv_model_backward_f32.argtypes = [vp, i64, i64, vp, vp, vp, ctypes.c_int, vp, vp, ctypes.c_int, i64, i64,
+                                                 vp, vp, vp, vp]
         L.mp_lcn_workspace_bytes.restype = ctypes.c_size_t
         L.mp_lcn_workspace_bytes.argtypes = [i64, i64, i64, i64, ctypes.c_int]
         L.mp_encode_lcn_f32.argtypes = [vp, i64, i64, vp, i64, i64, ctypes.c_int, vp, vp, vp, vp, vp,
@@ -211,8 +212,9 @@ def encode(signal, dict_unit, n_steps, path=MP_PATH_INCREMENTAL, flags=0, want_r
     return atom, lag, gain, residual
 
 
-def conv_model_backward(atoms, atom_idx, time_idx, value, residual_final, grad_channels):
-    """mp_conv_model_backward_f32: -> (grad_audio [B, N], grad_rows [B, K, L])."""
+def conv_model_backward(atoms, atom_idx, time_idx, value, residual_final, grad_channels, windowed=False):
+    """mp_conv_model_backward_f32: -> (grad_audio [B, N], grad_rows [B, K, L]).  grad_channels is [B, K, N], or
+    [B, K, L] (each event's own support only) with windowed=True."""
     atoms, value, residual_final = _f32(atoms), _f32(value), _f32(residual_final)
     grad_channels = _f32(grad_channels)
     atom_idx, time_idx = atom_idx.contiguous(), time_idx.contiguous()
@@ -220,14 +222,16 @@ def conv_model_backward(atoms, atom_idx, time_idx, value, residual_final, grad_c
     A, L = atoms.shape
     B, K = atom_idx.shape
     N = residual_final.shape[1]
-    assert grad_channels.shape == (B, K, N) and atom_idx.dtype == torch.int64 and time_idx.dtype == torch.int64
+    assert grad_channels.shape == (B, K, L if windowed else N)
+    assert atom_idx.dtype == torch.int64 and time_idx.dtype == torch.int64
     dev = atoms.device
     grad_audio = torch.empty((B, N), dtype=torch.float32, device=dev)
     grad_rows = torch.empty((B, K, L), dtype=torch.float32, device=dev)
     scratch = torch.empty((B, N), dtype=torch.float32, device=dev)
     with torch.cuda.device(dev):
         rc = lib().mp_conv_model_backward_f32(_ptr(atoms), A, L, _ptr(atom_idx), _ptr(time_idx), _ptr(value), K,
-                                              _ptr(residual_final), _ptr(grad_channels), B, N, _ptr(grad_audio),
+                                              _ptr(residual_final), _ptr(grad_channels), int(bool(windowed)), B, N,
+                                              _ptr(grad_audio),
                                               _ptr(grad_rows), _ptr(scratch), _stream(atoms))
     _check(rc, "mp_conv_model_backward_f32")
     scratch.record_stream(torch.cuda.current_stream(dev))

@@ -94,6 +94,78 @@ class _ConvModelFn(torch.autograd.Function):
         return lam, g_atoms, None, None
 
 
+class _ConvModelEventsFn(torch.autograd.Function):
+    """The same analysis loop, returning each event's own support only: windows [B, K, L] with
+    windows[b, i, j] = channel i of segment b at sample t_i + j (zero beyond the segment), plus the positions.
+    A loss that can work on the events (stft_iterative_loss) never forms the dense [B, K, N] channels."""
+
+    @staticmethod
+    def forward(ctx, audio, atoms, n_iterations, path):
+        B, N = audio.shape
+        A, L = atoms.shape
+        with torch.no_grad():
+            a_idx, t_idx, v, residual = _native.encode(audio, atoms, n_iterations, path=path, conv_model=True)
+            if path == _native.MP_PATH_FFT and bool(torch.isnan(v).any()):
+                a_idx, t_idx, v, residual = _native.encode(audio, atoms, n_iterations,
+                                                           path=_native.MP_PATH_INCREMENTAL, conv_model=True)
+            j = torch.arange(L, device=audio.device)
+            ok = (t_idx[:, :, None] + j[None, None, :]) < N
+            windows = torch.where(ok, (v * v)[:, :, None] * atoms[a_idx], torch.zeros((), device=audio.device))
+        ctx.save_for_backward(atoms, a_idx, t_idx, v, residual)
+        ctx.shape = (B, N, A, L, n_iterations)
+        ctx.mark_non_differentiable(t_idx)
+        return windows, t_idx
+
+    @staticmethod
+    def backward(ctx, grad_windows, _grad_t):
+        atoms, a_idx, t_idx, v, r = ctx.saved_tensors
+        B, N, A, L, K = ctx.shape
+        lam, rows = _native.conv_model_backward(atoms, a_idx, t_idx, v, r, grad_windows, windowed=True)
+        g_atoms = torch.zeros_like(atoms).index_add_(0, a_idx.reshape(-1), rows.reshape(B * K, L))
+        return lam, g_atoms, None, None
+
+
+def reference_stft(x, ws=2048, step=256):
+    """modules/stft.py:7-36 with pad=True, as mp.py:71-73 calls it: [B, C, T] -> [B, C, T // step, ws // 2 + 1]."""
+    frames = x.shape[-1] // step
+    x = torch.nn.functional.pad(x, (0, ws)).unfold(-1, ws, step)
+    x = x * torch.hann_window(ws, device=x.device)[None, None, :]
+    return torch.abs(torch.fft.rfft(x, norm="ortho"))[:, :, :frames, :]
+
+
+def stft_iterative_loss(model, target, ws=2048, step=256):
+    """iterative_loss(target, model(target), transform) of the reference's training loop (mp.py:102-104) for ITS
+    transform -- the magnitude STFT of modules/stft.py (window ws, hop step, pad=True) -- evaluated on the events.
+
+    With ratio_loss=False the greedy loss telescopes (modules/iterative.py:58-68: sum_i (|res_i| - |res_{i-1}|)),
+    so it equals  |T - sum_i S_i|_1 - |T|_1  with T = |STFT(target)| and S_i = |STFT(channel_i)|, whatever the
+    order of the channels.  A channel is one atom at one position: S_i is zero outside the <= (ws + L) / step + 1
+    frames its support touches, so only those frames are transformed (11 of 128 at the config-5 shape) and the
+    dense [B, K, N] channels and their [B, K, frames, bins] spectrograms (270 MB there) are never formed.
+    Same value and same gradients as the dense form (tests/test_gpu_api.py)."""
+    batch, _, n = target.shape
+    dev = _compute_device(model.atoms)
+    path = model.path if model.path is not None else _native.default_path(model.atom_samples)
+    x = target.reshape(batch, n).to(dev, torch.float32).contiguous()
+    windows, t_idx = _ConvModelEventsFn.apply(x, model.atoms[0].to(dev), model.n_iterations, path)
+    B, K, L = windows.shape
+    frames = n // step
+    slots = (ws + L) // step + 1
+    f0 = torch.clamp(torch.div(t_idx - ws, step, rounding_mode="floor") + 1, min=0)       # first frame touched
+    f = f0[:, :, None] + torch.arange(slots, device=dev)[None, None, :]                   # [B, K, S]
+    g = f[..., None] * step + torch.arange(ws, device=dev)                                # sample of frame entry
+    rel = g - t_idx[:, :, None, None]                                                     # index into the window
+    inside = (rel >= 0) & (rel < L) & (f[..., None] < frames)
+    pieces = torch.where(inside, torch.gather(windows[:, :, None, :].expand(B, K, slots, L), 3,
+                                              rel.clamp(0, L - 1)), torch.zeros((), device=dev))
+    mags = torch.abs(torch.fft.rfft(pieces * torch.hann_window(ws, device=dev), norm="ortho"))  # [B, K, S, bins]
+    bins = ws // 2 + 1
+    flat = (torch.arange(B, device=dev)[:, None, None] * frames + f.clamp(max=frames - 1)).reshape(-1)
+    summed = torch.zeros(B * frames, bins, device=dev).index_add_(0, flat, mags.reshape(-1, bins))
+    t_spec = reference_stft(x[:, None, :], ws, step).reshape(B * frames, bins)
+    return (t_spec - summed).abs().sum() - t_spec.abs().sum()
+
+
 class MatchingPursuit(nn.Module):
     """mp.py:32-67.  `path`: the native schedule (default: the fastest exact one)."""
 
@@ -139,10 +211,14 @@ def all_reduce_gradients(params, group=None, average=True):
 
 def train_step(model, optimizer, target, transform, group=None):
     """One step of mp.py:96-107: forward, iterative_loss, backward, (all-reduce,) optimiser step.
-    `target` is this rank's shard of the global batch.  Returns the local loss (a python float)."""
+    `target` is this rank's shard of the global batch.  Returns the local loss (a python float).
+    transform: a callable, as iterative_loss takes it -- or ("stft", ws, step) for the reference's own transform
+    (mp.py:71-73), which takes the event form of the loss (stft_iterative_loss)."""
     optimizer.zero_grad()
-    recon = model(target)
-    loss = iterative_loss(target, recon, transform)
+    if isinstance(transform, tuple) and transform and transform[0] == "stft":
+        loss = stft_iterative_loss(model, target, *transform[1:])
+    else:
+        loss = iterative_loss(target, model(target), transform)
     loss.backward()
     all_reduce_gradients(list(model.parameters()), group)
     optimizer.step()

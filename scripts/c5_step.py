@@ -26,4 +26,11 @@ for it in range(8):
     losses.append(train_step(model, opt, x, transform))
     torch.cuda.synchronize(); ts.append((time.perf_counter() - t0) * 1e3)
 print("loss", [round(l, 3) for l in losses])
+ts2 = []
+for it in range(8):
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    train_step(model, opt, x, ("stft", 2048, 256))
+    torch.cuda.synchronize(); ts2.append((time.perf_counter() - t0) * 1e3)
+print(f"train step, event form of the STFT loss (modules/stft.py transform, mp.py:71-73): median {np.median(ts2[2:]):.1f} ms "
+      f"({B * K / np.median(ts2[2:]) * 1e3:.0f} segment-iterations/s)")
 print(f"train step: median {np.median(ts[2:]):.1f} ms  ({B * K / np.median(ts[2:]) * 1e3:.0f} segment-iterations/s incl. backward and the STFT loss)")

@@ -440,3 +440,30 @@ def test_conv_model_backward_kernel_equals_the_stepwise_walk():
     lam, g_atoms, _, _ = _ConvModelFn.backward(ctx, g)
     assert (lam - lam_ref).abs().max().item() <= 1e-5 * lam_ref.abs().max().item()
     assert (g_atoms - g_ref).abs().max().item() <= 1e-5 * g_ref.abs().max().item()
+
+
+def test_event_form_of_the_stft_loss_equals_the_dense_form():
+    """stft_iterative_loss (the greedy loss of mp.py:102-104 for the reference's own STFT transform, evaluated on
+    the frames each event touches) against iterative_loss over the dense channels: same value, same gradient of
+    the dictionary -- including events cropped at the end of the segment."""
+    from mpcore.iterative import iterative_loss
+    from mpcore.model import MatchingPursuit, reference_stft, stft_iterative_loss
+    torch.manual_seed(5)
+    A, L, N, B, K, ws, step = 12, 96, 2048, 3, 6, 256, 64
+    model = MatchingPursuit(A, L, N, K).to(DEV)
+    with torch.no_grad():
+        model.atoms.copy_((torch.rand(1, A, L, device=DEV) - 0.5) * 0.3)
+    x = torch.randn(B, 1, N, device=DEV)
+    x[0, 0, N - 40:] += 8.0  # pulls an event to the very end of the first segment
+
+    def transform(t):
+        return reference_stft(t, ws, step).reshape(t.shape[0], t.shape[1], -1)
+
+    dense = iterative_loss(x, model(x), transform)
+    dense.backward()
+    g_dense = model.atoms.grad.clone()
+    model.atoms.grad = None
+    sparse = stft_iterative_loss(model, x, ws, step)
+    sparse.backward()
+    assert abs(sparse.item() - dense.item()) <= 2e-4 * abs(dense.item()) + 1e-3
+    assert (model.atoms.grad - g_dense).abs().max().item() <= 2e-4 * g_dense.abs().max().item()
