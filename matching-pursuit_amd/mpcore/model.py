@@ -26,6 +26,19 @@ from .iterative import iterative_loss
 from .matchingpursuit import _compute_device
 
 
+def _sum_rows_by_atom(rows, a_idx, n_atoms):
+    """g[a] = sum of the event rows [B, K, L] whose atom is a.  As a product with the one-hot selection matrix
+    (a small GEMM, deterministic) while that matrix is small; index_add_ (atomics -- 250 us at the config-5 shape,
+    where many events share an atom) beyond."""
+    B, K, L = rows.shape
+    if n_atoms * B * K <= (1 << 24):
+        onehot = torch.zeros(n_atoms, B * K, device=rows.device, dtype=rows.dtype)
+        onehot.scatter_(0, a_idx.reshape(1, -1), 1.0)
+        return onehot @ rows.reshape(B * K, L)
+    return torch.zeros(n_atoms, L, device=rows.device, dtype=rows.dtype).index_add_(0, a_idx.reshape(-1),
+                                                                                     rows.reshape(B * K, L))
+
+
 class _ConvModelFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, audio, atoms, n_iterations, path):
@@ -54,8 +67,7 @@ class _ConvModelFn(torch.autograd.Function):
         B, N, A, L, K = ctx.shape
         # the whole reverse walk in one launch (mp_conv_model_backward_f32), then one index_add over the events
         lam, rows = _native.conv_model_backward(atoms, a_idx, t_idx, v, r, grad_channels)
-        g_atoms = torch.zeros_like(atoms).index_add_(0, a_idx.reshape(-1), rows.reshape(B * K, L))
-        return lam, g_atoms, None, None
+        return lam, _sum_rows_by_atom(rows, a_idx, A), None, None
 
     @staticmethod
     def backward_stepwise(ctx, grad_channels):
@@ -121,8 +133,7 @@ class _ConvModelEventsFn(torch.autograd.Function):
         atoms, a_idx, t_idx, v, r = ctx.saved_tensors
         B, N, A, L, K = ctx.shape
         lam, rows = _native.conv_model_backward(atoms, a_idx, t_idx, v, r, grad_windows, windowed=True)
-        g_atoms = torch.zeros_like(atoms).index_add_(0, a_idx.reshape(-1), rows.reshape(B * K, L))
-        return lam, g_atoms, None, None
+        return lam, _sum_rows_by_atom(rows, a_idx, A), None, None
 
 
 def reference_stft(x, ws=2048, step=256):
