@@ -1336,7 +1336,7 @@ int fft_iteration(const Geom &g, const Workspace &w, const float *du, int K, int
             if ((rc = fft_lds_attr(fft_screen_split_kernel<SPLIT_LOGH>, lds_s))) return rc;
             hipLaunchKernelGGL(fft_screen_split_kernel<SPLIT_LOGH>, grid, dim3(C::WG), lds_s, st, w.xspec, w.pspec,
                                w.tw, dirty, w.wnorm, w.keys, w.ceps, g.N, g.A, g.NBLK, g.NAT, f.V, f.NW, FFT_TAU, pps,
-                               (int)seg_fast, (float *)nullptr, (unsigned *)nullptr);
+                               (int)seg_fast);
         } else if (f.split) {
             hipLaunchKernelGGL(fft_correlate_split_kernel<SPLIT_LOGH>, dim3(2 * nw, g.NAT, (unsigned)g.B), dim3(256), lds, st,
                                w.xspec, w.pspec, w.tw, dirty, w.wnorm, w.keys, w.ceps, g.N, g.A, g.NBLK, g.NAT, f.V,
