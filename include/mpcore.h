@@ -218,13 +218,16 @@ int mp_conv_model_backward_f32(const float *atoms, int64_t A, int64_t L, const i
  * [offsets[g], offsets[g+1]) of ev_batch / ev_lag / ev_rows [E, L] (= d[atom] * value as materialised at
  * encode time) / ev_norm [E] (= ||row||).  residual [B, N] starts as the ORIGINAL signal (:367) and is
  * updated in place; dict_work [A, L] receives the new unit-norm atoms; sparse_zeroed is a [B, N] scratch that
- * must be zero on entry and is zero again on return.  Single-device form; a multi-GPU run needs the per-atom
- * all-reduce of mp_gather_sum_f32 between the two halves and keeps the step-by-step form.
+ * must be zero on entry and is zero again on return.  overlap [n_groups] or NULL: overlap[g] == 0 promises that
+ * no two events of group g share a sample (same segment, lags less than L apart), which lets the kernel apply
+ * the group's events all at once (same arithmetic, an eighth of the barriers); NULL or nonzero: one by one.
+ * Single-device form; a multi-GPU run needs the per-atom all-reduce of mp_gather_sum_f32 between the two halves
+ * and keeps the step-by-step form.
  */
 int mp_dictionary_update_f32(float *residual, float *sparse_zeroed, int64_t B, int64_t N, float *dict_work, int64_t A,
                              int64_t L, const int64_t *order, const int64_t *offsets, int64_t n_groups,
                              const int64_t *ev_batch, const int64_t *ev_lag, const float *ev_rows,
-                             const float *ev_norm, float eps, void *stream);
+                             const float *ev_norm, float eps, const int *overlap, void *stream);
 
 #ifdef __cplusplus
 }

@@ -902,22 +902,77 @@ __global__ __launch_bounds__(1024) void dictionary_update_kernel(
     float *__restrict__ residual, float *__restrict__ sparse, int64_t N, float *__restrict__ d_work, int64_t L,
     const int64_t *__restrict__ order, const int64_t *__restrict__ off, int64_t n_groups,
     const int64_t *__restrict__ ev_batch, const int64_t *__restrict__ ev_lag, const float *__restrict__ ev_rows,
-    const float *__restrict__ ev_norm, float eps) {
+    const float *__restrict__ ev_norm, float eps, const int *__restrict__ overlap, int64_t win_cap) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float *nw = reinterpret_cast<float *>(smem);  // the new atom, L floats
+    float *win = nw + L;                          // win_cap floats: an atom's residual windows (see below)
     __shared__ float s_den;
     const int tid = threadIdx.x;
     for (int64_t g = 0; g < n_groups; ++g) {
         const int64_t e0 = off[g], e1 = off[g + 1];
+        // An atom none of whose events overlap (overlap[g] == 0: the caller checked -- almost every atom) needs no
+        // staging in `sparse` and no event-after-event order: 0 + row == row exactly, so adding the rows straight
+        // into the residual, all events at once, is the same arithmetic with 5 barriers per atom instead of 4 n + 3.
+        const bool apart = overlap && overlap[g] == 0;
+        const int64_t span = (e1 - e0) * L;
+        // ... and when the atom's windows fit LDS (n L floats) they stay there between the add-back and the
+        // subtraction: one global read and one global write per sample, two memory round trips per atom
+        const bool in_lds = apart && span <= win_cap;
+        if (in_lds) {
+            // work units of 64 samples, dealt to the 16 wavefronts (no per-element index division)
+            const int wv = __builtin_amdgcn_readfirstlane(tid >> 6), ln = tid & 63;
+            const int chunks = (int)((L + 63) / 64), units = (int)(e1 - e0) * chunks;
+            for (int u = wv; u < units; u += 16) {
+                const int el = u / chunks, sidx = (u - el * chunks) * 64 + ln;
+                const int64_t e = e0 + el, t = ev_lag[e] + sidx;
+                if (sidx < L)
+                    win[(int64_t)el * L + sidx] = t < N ? __fadd_rn(residual[ev_batch[e] * N + t], ev_rows[e * L + sidx]) : 0.0f;
+            }
+            __syncthreads();
+            for (int64_t j = tid; j < L; j += 1024) {
+                double acc = 0.0;
+                for (int64_t e = 0; e < e1 - e0; ++e) acc += (double)win[e * L + j];
+                nw[j] = (float)acc;
+            }
+            __syncthreads();
+            if (tid < 64) {
+                const double ss = row_sum_squares(nw, L, tid);
+                if (tid == 0) s_den = __fadd_rn(sqrt_rn_f32((float)ss), eps);
+            }
+            __syncthreads();
+            const float den = s_den;
+            float *drow = d_work + order[g] * L;
+            for (int64_t j = tid; j < L; j += 1024) {
+                const float v = div_rn_f32(nw[j], den);
+                nw[j] = v;
+                drow[j] = v;
+            }
+            __syncthreads();
+            for (int u = wv; u < units; u += 16) {
+                const int el = u / chunks, sidx = (u - el * chunks) * 64 + ln;
+                const int64_t e = e0 + el, t = ev_lag[e] + sidx;
+                if (sidx < L && t < N)
+                    residual[ev_batch[e] * N + t] = __fsub_rn(win[(int64_t)el * L + sidx], __fmul_rn(nw[sidx], ev_norm[e]));
+            }
+            __syncthreads();  // the next atom reads what this one wrote
+            continue;
+        }
+        if (apart) {
+            for (int64_t idx = tid; idx < span; idx += 1024) {
+                const int64_t e = e0 + idx / L, sidx = idx % L, t = ev_lag[e] + sidx;
+                if (t < N) residual[ev_batch[e] * N + t] = __fadd_rn(residual[ev_batch[e] * N + t], ev_rows[e * L + sidx]);
+            }
+            __syncthreads();
+        }
         // add the atom's events back: accumulate in `sparse` (event after event: they may overlap), then move
-        for (int64_t e = e0; e < e1; ++e) {
+        for (int64_t e = e0; e < e1 && !apart; ++e) {
             float *sp = sparse + ev_batch[e] * N + ev_lag[e];
             const float *row = ev_rows + e * L;
             const int64_t len = N - ev_lag[e] < L ? N - ev_lag[e] : L;
             for (int64_t s = tid; s < len; s += 1024) sp[s] = __fadd_rn(sp[s], row[s]);
             __syncthreads();
         }
-        for (int64_t e = e0; e < e1; ++e) {
+        for (int64_t e = e0; e < e1 && !apart; ++e) {
             const int64_t base = ev_batch[e] * N + ev_lag[e];
             const int64_t len = N - ev_lag[e] < L ? N - ev_lag[e] : L;
             for (int64_t s = tid; s < len; s += 1024) {
@@ -950,14 +1005,22 @@ __global__ __launch_bounds__(1024) void dictionary_update_kernel(
         }
         __syncthreads();
         // take the new atom out again with the magnitudes the old instances had
-        for (int64_t e = e0; e < e1; ++e) {
+        if (apart) {
+            for (int64_t idx = tid; idx < span; idx += 1024) {
+                const int64_t e = e0 + idx / L, sidx = idx % L, t = ev_lag[e] + sidx;
+                if (t < N)
+                    residual[ev_batch[e] * N + t] = __fsub_rn(residual[ev_batch[e] * N + t], __fmul_rn(nw[sidx], ev_norm[e]));
+            }
+            __syncthreads();
+        }
+        for (int64_t e = e0; e < e1 && !apart; ++e) {
             float *sp = sparse + ev_batch[e] * N + ev_lag[e];
             const float nrm = ev_norm[e];
             const int64_t len = N - ev_lag[e] < L ? N - ev_lag[e] : L;
             for (int64_t s = tid; s < len; s += 1024) sp[s] = __fadd_rn(sp[s], __fmul_rn(nw[s], nrm));
             __syncthreads();
         }
-        for (int64_t e = e0; e < e1; ++e) {
+        for (int64_t e = e0; e < e1 && !apart; ++e) {
             const int64_t base = ev_batch[e] * N + ev_lag[e];
             const int64_t len = N - ev_lag[e] < L ? N - ev_lag[e] : L;
             for (int64_t s = tid; s < len; s += 1024) {
@@ -1823,18 +1886,21 @@ int mp_gather_sum_f32(const float *x, int64_t B, int64_t N, const int64_t *batch
 int mp_dictionary_update_f32(float *residual, float *sparse_zeroed, int64_t B, int64_t N, float *dict_work, int64_t A,
                              int64_t L, const int64_t *order, const int64_t *offsets, int64_t n_groups,
                              const int64_t *ev_batch, const int64_t *ev_lag, const float *ev_rows,
-                             const float *ev_norm, float eps, void *stream) {
+                             const float *ev_norm, float eps, const int *overlap, void *stream) {
     if (n_groups == 0) return MP_OK;
     if (!residual || !sparse_zeroed || !dict_work || !order || !offsets || !ev_batch || !ev_lag || !ev_rows ||
         !ev_norm || B <= 0 || N <= 0 || A <= 0 || L <= 0 || n_groups < 0)
         return fail(MP_ERR_ARG, "mp_dictionary_update_f32: bad arguments%s");
-    const size_t lds = (size_t)L * sizeof(float);
-    if (lds > 150 * 1024) return fail(MP_ERR_UNSUPPORTED, "mp_dictionary_update_f32: atom too long for LDS%s");
+    if ((size_t)L * sizeof(float) > 150 * 1024) return fail(MP_ERR_UNSUPPORTED, "mp_dictionary_update_f32: atom too long for LDS%s");
+    // the new atom, and what is left of 144 KiB for the windows of an atom's events
+    const int64_t win_cap = overlap ? (int64_t)((144 * 1024 - (size_t)L * sizeof(float)) / sizeof(float)) : 0;
+    const size_t lds = ((size_t)L + (size_t)(win_cap > 0 ? win_cap : 0)) * sizeof(float);
     if (lds > 64 * 1024)
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(dictionary_update_kernel),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(dictionary_update_kernel, dim3(1), dim3(1024), lds, static_cast<hipStream_t>(stream), residual,
-                       sparse_zeroed, N, dict_work, L, order, offsets, n_groups, ev_batch, ev_lag, ev_rows, ev_norm, eps);
+                       sparse_zeroed, N, dict_work, L, order, offsets, n_groups, ev_batch, ev_lag, ev_rows, ev_norm, eps,
+                       overlap, win_cap > 0 ? win_cap : 0);
     HIP_TRY(hipGetLastError());
     return MP_OK;
 }

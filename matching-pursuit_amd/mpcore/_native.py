@@ -76,7 +76,7 @@ def lib():
         L.mp_scatter_rows_f32.argtypes = [vp, vp, vp, i64, i64, vp, i64, i64, vp]
         L.mp_gather_sum_f32.argtypes = [vp, i64, i64, vp, vp, i64, i64, vp, vp]
         L.mp_dictionary_update_f32.argtypes = [vp, vp, i64, i64, vp, i64, i64, vp, vp, i64, vp, vp, vp, vp,
-                                               ctypes.c_float, vp]
+                                               ctypes.c_float, vp, vp]
         L.mp_fft_c2c_f32.argtypes = [vp, vp, ctypes.c_int, i64, ctypes.c_int, vp, vp]
         for name in EXPORTS:
             getattr(L, name)
@@ -408,7 +408,8 @@ def gather_sum(x, batch, lag, L):
     return out
 
 
-def dictionary_update(residual, d_work, order, offsets, ev_batch, ev_lag, ev_rows, ev_norm, eps=1e-8):
+def dictionary_update(residual, d_work, order, offsets, ev_batch, ev_lag, ev_rows, ev_norm, eps=1e-8,
+                      one_by_one=False):
     """mp_dictionary_update_f32: the atom-by-atom loop of dictionary_learning_step in one launch.
     residual [B, N] and d_work [A, L] are updated in place."""
     _require_cuda(residual, d_work)
@@ -420,9 +421,20 @@ def dictionary_update(residual, d_work, order, offsets, ev_batch, ev_lag, ev_row
     ev_batch, ev_lag = _i64(ev_batch, dev), _i64(ev_lag, dev)
     ev_rows, ev_norm = _f32(ev_rows), _f32(ev_norm)
     sparse = torch.zeros_like(residual)
+    # which atoms have two events sharing a sample (same segment, lags < L apart)?  Sort the events by
+    # (group, segment, lag) and look at neighbours -- a few small device operations, no synchronisation
+    n_groups, n_events = order.numel(), ev_batch.numel()
+    overlap = torch.zeros(max(n_groups, 1), dtype=torch.int32, device=dev)
+    if one_by_one:  # (tests) every atom's events one after another, as if they all overlapped
+        overlap.fill_(1)
+    elif n_events > 1:
+        group = torch.searchsorted(offsets[1:].contiguous(), torch.arange(n_events, device=dev), right=True)
+        key, _ = torch.sort((group * B + ev_batch) * N + ev_lag)
+        near = ((key[1:] // N) == (key[:-1] // N)) & ((key[1:] - key[:-1]) < L)
+        overlap.scatter_reduce_(0, key[1:] // (N * B), near.to(torch.int32), "amax")
     with torch.cuda.device(dev):
         rc = lib().mp_dictionary_update_f32(_ptr(residual), _ptr(sparse), B, N, _ptr(d_work), A, L, _ptr(order),
                                             _ptr(offsets), order.numel(), _ptr(ev_batch), _ptr(ev_lag), _ptr(ev_rows),
-                                            _ptr(ev_norm), ctypes.c_float(eps), _stream(residual))
+                                            _ptr(ev_norm), ctypes.c_float(eps), _ptr(overlap), _stream(residual))
     _check(rc, "mp_dictionary_update_f32")
     sparse.record_stream(torch.cuda.current_stream(dev))

@@ -467,3 +467,38 @@ def test_event_form_of_the_stft_loss_equals_the_dense_form():
     sparse.backward()
     assert abs(sparse.item() - dense.item()) <= 2e-4 * abs(dense.item()) + 1e-3
     assert (model.atoms.grad - g_dense).abs().max().item() <= 2e-4 * g_dense.abs().max().item()
+
+
+def test_dictionary_update_fast_path_is_bit_identical_and_overlaps_are_detected(oracle):
+    """mp_dictionary_update_f32 applies an atom's events all at once when none of them share a sample, one by one
+    (staged in the scratch map, as the reference's dense tensors do) when they do.  A batch where one atom is
+    planted twice 20 samples apart in the same segment must take the slow path for that atom -- and the whole
+    step must equal both the all-one-by-one run (bit for bit) and the oracle."""
+    from mpcore import _native as nat
+    rng = np.random.default_rng(77)
+    A, L, N, B, K = 10, 48, 700, 3, 6
+    d = synth.make_dictionary(A, L, seed=77)
+    du = oracle.unit_norm(d)
+    x = (0.01 * rng.standard_normal((B, N))).astype(np.float32)
+    x[0, 100:100 + L] += 3.0 * du[4]
+    x[0, 120:120 + L] += 2.5 * du[4]          # the same atom again, overlapping the first instance
+    x[1, 300:300 + L] += 2.0 * du[4]
+    x[2, 50:50 + L] += 2.2 * du[7]
+    x[2, 400:400 + L] += 1.9 * du[7]          # same atom, same segment, far apart: no overlap
+    xt, dt = torch.from_numpy(x).to(DEV)[:, None, :], torch.from_numpy(d).to(DEV)
+    got = mp.dictionary_learning_step(xt, dt, n_steps=K)
+    want = oracle.dictionary_learning_step(x, d, K)
+    assert np.abs(got.cpu().numpy() - want).max() <= 2e-6
+    calls = []
+    real = nat.dictionary_update
+
+    def spy(*args, **kw):
+        calls.append(1)
+        return real(*args, one_by_one=True, **kw)
+
+    nat.dictionary_update = spy
+    try:
+        slow = mp.dictionary_learning_step(xt, dt, n_steps=K)
+    finally:
+        nat.dictionary_update = real
+    assert calls and torch.equal(slow, got)
