@@ -501,6 +501,7 @@ class _SparseFeatureMapFn(torch.autograd.Function):
         lam = g_res.clone() if g_res is not None else torch.zeros(B, N, device=dev)
         g_fm = g_fm if g_fm is not None else torch.zeros(B, A, N, device=dev)
         r = r.clone()
+        d_spec = torch.fft.rfft(d_unit, n=N + L)                       # [A, F], once
         for i in range(K - 1, -1, -1):
             a, p, v = atom[:, i], lag[:, i], gain[:, i]
             da = d_unit[a]                                             # [B, L]
@@ -509,13 +510,20 @@ class _SparseFeatureMapFn(torch.autograd.Function):
             posc = pos.clamp(max=N - 1)
             r.scatter_add_(1, posc, torch.where(ok, v[:, None] * da, torch.zeros_like(da)))   # r_i
             f = _native.feature_map(r, d_unit)                         # [B, A, N], exact chains
-            s = torch.softmax(f.reshape(B, -1), dim=-1).reshape(B, A, N)
+            # softmax over the A*N cells of each segment, as two-stage reductions (lags, then atoms): a row of
+            # 16.8 M cells reduced by torch.softmax / sum(dim=(1, 2)) is one workgroup's work -- 10 ms a call
+            m = f.amax(dim=2).amax(dim=1)
+            s = torch.exp(f - m[:, None, None])
+            s = s / s.sum(dim=2).sum(dim=1)[:, None, None]
             gf = g_fm * f
-            c = (gf * s).sum(dim=(1, 2), keepdim=True)
+            c = (gf * s).sum(dim=2).sum(dim=1)[:, None, None]
             w = s * (gf - c)
             lam_win = torch.where(ok, lam.gather(1, posc), torch.zeros_like(da))
             w[bidx, a, p] += g_fm[bidx, a, p] - (lam_win * da).sum(-1)
-            lam = lam + F.conv_transpose1d(w, d_unit.view(A, 1, L))[:, 0, :N]
+            # lam += conv_transpose1d(w, d)[:N] = sum_a (w_a * d_a)[:N], as one spectral accumulation: 13x fewer
+            # flops than the dense contraction (2 A L N per segment) and none of MIOpen's search on first use
+            ws = torch.fft.rfft(w, n=N + L)                            # [B, A, F]
+            lam = lam + torch.fft.irfft((ws * d_spec[None]).sum(1), n=N + L)[:, :N]
         return lam, None, None
 
 
