@@ -228,6 +228,10 @@ def test_bad_arguments_fail_loudly():
         nat.encode(torch.zeros(1, 64, device=DEV), du, 1, path=77)
     with pytest.raises(nat.NativeError):  # a transform must fit LDS whole or as two halves: atoms > 10859 samples
         nat.encode(torch.zeros(1, 16000, device=DEV), torch.rand(2, 11000, device=DEV), 1, path=nat.MP_PATH_FFT)
+    with pytest.raises(nat.NativeError):  # flat (atom, lag) indices are 32-bit: A * N must stay below 2^32
+        nat.encode(torch.zeros(1, 4096, device=DEV), torch.zeros(1 << 20, 1, device=DEV), 1, path=nat.MP_PATH_INCREMENTAL)
+    with pytest.raises(nat.NativeError):
+        nat.encode_lcn(torch.zeros(1, 4096, device=DEV), torch.zeros(1 << 20, 1, device=DEV), 1)
     # ... and the default schedule falls back to the incremental one for those
     a, l, g, r = nat.encode_checked(torch.rand(1, 16000, device=DEV), nat.unit_norm(torch.rand(2, 11000, device=DEV)), 1)
     assert a.shape == (1, 1) and not torch.isnan(g).any()
