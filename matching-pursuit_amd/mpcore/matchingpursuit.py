@@ -9,6 +9,7 @@ raises `NativeError`.
 """
 from collections import defaultdict
 
+import numpy as np
 import torch
 from torch import nn
 from torch.nn import functional as F
@@ -352,16 +353,15 @@ def group_events_by_atom(atom, order, n_atoms):
     `order`, each group in (step, batch) order -- the layout of flatten_atom_dict (:61-65) -- and the
     number of events per group.  Atoms of `order` absent from `atom` (another rank's) get 0."""
     B, K = atom.shape
-    rank_of = torch.full((n_atoms,), len(order), dtype=torch.int64)
+    a = atom.cpu().numpy()  # (numpy: a dozen small host tensor operations cost 2 ms here, these 0.3 ms)
+    rank_of = np.full(n_atoms, len(order), dtype=np.int64)
     if len(order):
-        rank_of[torch.tensor(order, dtype=torch.int64)] = torch.arange(len(order))
-    step_idx = torch.arange(K)[None, :].expand(B, K)
-    batch_idx = torch.arange(B)[:, None].expand(B, K)
-    r = rank_of[atom]
-    sort_key = (r * K + step_idx) * max(B, 1) + batch_idx
-    perm = torch.argsort(sort_key.reshape(-1), stable=True)
-    counts = torch.bincount(r.reshape(-1), minlength=len(order) + 1).tolist()[: len(order)]
-    return perm, counts
+        rank_of[np.asarray(order, dtype=np.int64)] = np.arange(len(order), dtype=np.int64)
+    r = rank_of[a]
+    sort_key = (r * K + np.arange(K, dtype=np.int64)[None, :]) * max(B, 1) + np.arange(B, dtype=np.int64)[:, None]
+    perm = np.argsort(sort_key.reshape(-1), kind="stable")
+    counts = np.bincount(r.reshape(-1), minlength=len(order) + 1)[: len(order)].tolist()
+    return torch.from_numpy(perm), counts
 
 
 # --------------------------------------------------------------------------------------------
