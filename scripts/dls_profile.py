@@ -1,3 +1,5 @@
+"""torch-profiler table of one dictionary_learning_step (modules/matchingpursuit.py:348-419) at the headline shape:
+device time per kernel (the encode's screen / select kernels and the fused dictionary_update_kernel)."""
 import os, sys, time
 import numpy as np, torch
 sys.path.insert(0, "matching-pursuit_amd")

@@ -1,3 +1,5 @@
+"""Headline shape: plain launches against the replay of a captured hipGraph (mpcore.EncodePlan), for the one-stream
+schedule and the two-sub-batch default, with the sampled event profiling on and off."""
 import os, sys, time
 import numpy as np, torch
 sys.path.insert(0, "matching-pursuit_amd")

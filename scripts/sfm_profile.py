@@ -1,3 +1,5 @@
+"""torch-profiler table of sparse_coding_loss forward + backward (modules/matchingpursuit.py:68-146) at the headline
+dictionary, 4 segments x 16 steps: which tensor operations the reference-defined dense gradient spends its time in."""
 import os, sys, time
 import numpy as np, torch
 sys.path.insert(0, "matching-pursuit_amd")
