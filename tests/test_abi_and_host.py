@@ -144,3 +144,23 @@ def test_band_split_matches_reference_golden(golden_dir):
     d1 = d1 / (torch.norm(d1, dim=-1, keepdim=True) + 1e-8)
     ra = dec.fft_resample(d1.view(8, 1, 32), 64, False)
     assert np.abs(ra.numpy() - z["resampled_atoms_band1"]).max() <= 2e-6
+
+
+def test_hot_kernels_keep_their_register_budget():
+    """The register screen kernels live at the 128-VGPR edge of four wavefronts per SIMD; a change elsewhere in
+    the translation unit can tip them into spilling (it happened: 24 spilled registers in the headline kernel from
+    an unrelated template parameter).  Read the built code object's metadata -- no compile, no GPU."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("kernel_resources", os.path.join(REPO, "scripts", "kernel_resources.py"))
+    kr = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(kr)
+    if not os.path.exists(kr.LIB) or not os.path.exists(os.path.join(kr.LLVM, "clang-offload-bundler")):
+        pytest.skip("needs the built library and the ROCm LLVM tools")
+    res = kr.kernel_resources()
+    assert len(res) > 50
+    screens = {n: r for n, r in res.items() if "17fft_screen_kernelILi" in n}
+    assert len(screens) == 5
+    for name, r in screens.items():
+        assert r["spill"] == 0 and r["vgpr"] <= 128, (name, r)
+    persistent = {n: r for n, r in res.items() if "correlate_persistent_kernel" in n}
+    assert persistent and all(r["spill"] == 0 for r in persistent.values())
