@@ -57,7 +57,7 @@ extern "C" {
 #define MP_FLAG_FFT_FUSED 1024  /* MP_PATH_FFT: the whole-cell one-kernel select (default only for >= 65536 cells per
                                    segment)                                                                        */
 #define MP_FLAG_OVERLAP 2048    /* sub-batches on forked internal streams (joined before returning); default for
-                                   MP_PATH_FFT from 64 segments of < 65536 cells up                               */
+                                   MP_PATH_FFT from 48 segments of < 65536 cells up                               */
 #define MP_FLAG_NO_OVERLAP 4096 /* never split the batch                                                          */
 #define MP_FLAG_FFT_NO_QUARTER 8192 /* MP_PATH_FFT: segments of <= 16384 cells through scan+refine / select-B instead
                                        of the one-kernel quarter-cell select (default when the batch is split)    */
@@ -81,7 +81,7 @@ int mp_profile_enable(int every);
 /* Tuning hook (process-wide; results never depend on it as long as tau stays above the transform error):
  *   MP_TUNE_TAU         the FFT screen's error bound per unit of window norm (default 2e-5)
  *   MP_TUNE_SCREEN_PPS  atom pairs per transform slot in the screen kernel (0 = heuristic)
- *   MP_TUNE_GROUPS      sub-batches when the batch is split over forked streams (2..4, default 2)     */
+ *   MP_TUNE_GROUPS      sub-batches when the batch is split over forked streams (2..4, default 4)     */
 #define MP_TUNE_TAU 1
 #define MP_TUNE_SCREEN_PPS 2
 #define MP_TUNE_GROUPS 3

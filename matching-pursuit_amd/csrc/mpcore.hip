@@ -1283,7 +1283,7 @@ int fft_lds_attr(K kern, size_t bytes) {
 }
 
 int screen_pps_override = 0;  // tuning hook (mp_tune)
-int overlap_groups = 2;        // sub-batches when the batch is split over forked streams (mp_tune)
+int overlap_groups = 4;        // sub-batches when the batch is split over forked streams (mp_tune)
 // screen error bound per unit of window norm: measured max |fft - chain| is
 // 6e-7 ||window|| (scripts/screen_error.py), so 2e-5 is a >30x margin; mp_tune(MP_TUNE_TAU, x) overrides
 float FFT_TAU = 2.0e-5f;
@@ -1507,16 +1507,75 @@ constexpr int MAX_GROUPS = 4;
 struct StreamPool {
     hipStream_t streams[MAX_GROUPS];
     hipEvent_t fork, join[MAX_GROUPS];
+    int n_concurrent;  // streams[0 .. n_concurrent) were seen to run kernels side by side (see stream_pool)
 };
-StreamPool *stream_pool() {  // one pool per host thread and device, created on first use, never destroyed
+
+// busy-wait for about `ticks` of the 100 MHz wall clock (self-test of stream concurrency)
+__global__ void spin_kernel(long long ticks, int *sink) {
+    const long long t0 = wall_clock64();
+    while (wall_clock64() - t0 < ticks) {}
+    if (sink && ticks < 0) *sink = 1;
+}
+
+// Two streams that run kernels side by side finish two spins in about the time of one; streams that share a
+// hardware queue take twice as long.  Returns elapsed(two streams) / elapsed(one spin), or a negative value.
+float stream_pair_ratio(hipStream_t a, hipStream_t b) {
+    hipEvent_t e0, ea, eb;
+    if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&ea) != hipSuccess || hipEventCreate(&eb) != hipSuccess) return -1.f;
+    const long long ticks = 4000;  // 40 us
+    float one = 0.f, ta = 0.f, tb = 0.f;
+    bool ok = hipEventRecord(e0, a) == hipSuccess;
+    hipLaunchKernelGGL(spin_kernel, dim3(1), dim3(64), 0, a, ticks, (int *)nullptr);
+    ok = ok && hipEventRecord(ea, a) == hipSuccess && hipEventSynchronize(ea) == hipSuccess &&
+         hipEventElapsedTime(&one, e0, ea) == hipSuccess;
+    ok = ok && hipEventRecord(e0, a) == hipSuccess && hipStreamWaitEvent(b, e0, 0) == hipSuccess;
+    hipLaunchKernelGGL(spin_kernel, dim3(1), dim3(64), 0, a, ticks, (int *)nullptr);
+    hipLaunchKernelGGL(spin_kernel, dim3(1), dim3(64), 0, b, ticks, (int *)nullptr);
+    ok = ok && hipEventRecord(ea, a) == hipSuccess && hipEventRecord(eb, b) == hipSuccess &&
+         hipEventSynchronize(ea) == hipSuccess && hipEventSynchronize(eb) == hipSuccess &&
+         hipEventElapsedTime(&ta, e0, ea) == hipSuccess && hipEventElapsedTime(&tb, e0, eb) == hipSuccess;
+    hipEventDestroy(e0); hipEventDestroy(ea); hipEventDestroy(eb);
+    if (!ok || one <= 0.f) return -1.f;
+    return (ta > tb ? ta : tb) / one;
+}
+// One pool per host thread and device, created on first use, never destroyed.
+// ROCm multiplexes streams onto a few hardware queues (least-used queue at creation time), and two streams on one
+// queue run their kernels one after the other: sub-batches on such a pair are SLOWER than one stream.  Which
+// streams collide depends on what the process created before -- measured: after any hipGraph capture in the
+// process the first two streams created here shared a queue and the default schedule fell from 840 k to 590 k
+// segment-iterations/s (scripts/after_capture.py).  So the pool is chosen, not assumed: of eight candidates, keep
+// those that a 40 us spin test shows running side by side with every stream already kept (a few ms, once).
+StreamPool *stream_pool(hipStream_t caller) {
     static thread_local StreamPool pools[16];
     static thread_local bool ready[16] = {false};
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return nullptr;
     if (!ready[dev]) {
         StreamPool &p = pools[dev];
+        constexpr int NCAND = 8;
+        hipStream_t cand[NCAND];
+        for (int c = 0; c < NCAND; ++c)
+            if (hipStreamCreateWithFlags(&cand[c], hipStreamNonBlocking) != hipSuccess) return nullptr;
+        hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+        const bool can_test = hipStreamIsCapturing(caller, &cap) == hipSuccess && cap == hipStreamCaptureStatusNone;
+        int kept[MAX_GROUPS], n = 0;
+        bool used[NCAND] = {false};
+        for (int c = 0; c < NCAND && n < MAX_GROUPS; ++c) {
+            bool apart = true;
+            for (int k = 0; k < n && apart && can_test; ++k) {
+                const float r = stream_pair_ratio(cand[kept[k]], cand[c]);
+                apart = r > 0.f && r < 1.5f;
+            }
+            if (apart) { kept[n++] = c; used[c] = true; }
+        }
+        p.n_concurrent = can_test ? n : 2;  // (created inside a capture: untested, the first two as before)
+        for (int c = 0, q = n; c < NCAND; ++c) {  // fill the rest of the pool, drop what is left
+            if (used[c]) continue;
+            if (q < MAX_GROUPS) kept[q++] = c, used[c] = true;
+            else (void)hipStreamDestroy(cand[c]);
+        }
         for (int q = 0; q < MAX_GROUPS; ++q) {
-            if (hipStreamCreateWithFlags(&p.streams[q], hipStreamNonBlocking) != hipSuccess) return nullptr;
+            p.streams[q] = cand[kept[q]];
             if (hipEventCreateWithFlags(&p.join[q], hipEventDisableTiming) != hipSuccess) return nullptr;
         }
         if (hipEventCreateWithFlags(&p.fork, hipEventDisableTiming) != hipSuccess) return nullptr;
@@ -1648,20 +1707,25 @@ static int encode_impl(const float *signal, int64_t B, int64_t N, const float *d
     // Segments are independent, so the batch can be cut into sub-batches on forked streams -- while one
     // is in its short, latency-bound select kernels the others keep the CUs busy.  Joined back into the
     // caller's stream before returning; fork/join by events is graph-capture safe.
-    // Measured (scripts/fft_ab.py): FFT schedule, headline shape 5.49 -> 5.25 ms per encode with two
-    // sub-batches; +1 % on the incremental MFMA schedule; -4 % at the config-4 shape, whose screens fill the
-    // GPU on their own, and -6..-20 % with 32 segments (half-batches of 16 are too small).  Default for
-    // MP_PATH_FFT from 64 segments up when a segment has < 65536 cells
-    // (MP_FLAG_NO_OVERLAP turns it off), opt-in elsewhere (MP_FLAG_OVERLAP).
+    // Measured (scripts/sub_batches.py, headline dictionary, one synchronised encode at a time; segment-iterations/s
+    // with 1 / 2 / 4 sub-batches): 16 segments 409 / 367 / 377 k, 32: 632 / 621 / 631 k, 48: 709 / 759 / 780 k,
+    // 64: 814 / 846 / 877 k, 128: 899 / 1041 / 1050 k, 256: 985 / 1176 / 1180 k; +1 % on the incremental MFMA
+    // schedule; -4 % at the config-4 shape, whose screens fill the GPU on their own.  Default for MP_PATH_FFT:
+    // four sub-batches from 48 segments up when a segment has < 65536 cells (MP_FLAG_NO_OVERLAP turns it off),
+    // opt-in elsewhere (MP_FLAG_OVERLAP).  Only on streams seen to run side by side (stream_pool).
     int n_groups = 1;
     if (K > 0 && !(flags & MP_FLAG_NO_OVERLAP) &&
         (((flags & MP_FLAG_OVERLAP) && B >= 8) ||
-         (path == MP_PATH_FFT && B >= 64 && (int64_t)g.NBLK * g.NAT < 65536)))  // big screens fill the GPU alone
-        n_groups = overlap_groups >= 2 && overlap_groups <= MAX_GROUPS ? overlap_groups : 2;
+         (path == MP_PATH_FFT && B >= 48 && (int64_t)g.NBLK * g.NAT < 65536)))  // big screens fill the GPU alone
+        n_groups = overlap_groups >= 2 && overlap_groups <= MAX_GROUPS ? overlap_groups : 4;
     StreamPool *pool = nullptr;
     if (n_groups > 1) {
-        pool = stream_pool();
+        pool = stream_pool(st);
         if (!pool) return fail(MP_ERR_HIP, "could not create internal streams%s");
+        if (n_groups > pool->n_concurrent) n_groups = pool->n_concurrent;  // never sub-batches on one hardware queue
+        if (n_groups < 2) { n_groups = 1; pool = nullptr; }
+    }
+    if (pool) {
         HIP_TRY(hipEventRecord(pool->fork, st));
         for (int q = 0; q < n_groups; ++q) HIP_TRY(hipStreamWaitEvent(pool->streams[q], pool->fork, 0));
     }
@@ -1918,6 +1982,13 @@ int mp_conv_model_backward_f32(const float *atoms, int64_t A, int64_t L, const i
                        windowed);
     HIP_TRY(hipGetLastError());
     return MP_OK;
+}
+
+/* test / diagnosis hook: concurrency ratio of the internal streams q0 and q1 (see stream_pair_ratio) */
+float mp_stream_pair_ratio(int q0, int q1) {
+    StreamPool *p = stream_pool(nullptr);
+    if (!p || q0 < 0 || q1 < 0 || q0 >= MAX_GROUPS || q1 >= MAX_GROUPS) return -1.f;
+    return stream_pair_ratio(p->streams[q0], p->streams[q1]);
 }
 
 }  // extern "C"
