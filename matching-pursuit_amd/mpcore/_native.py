@@ -242,8 +242,11 @@ class EncodePlan:
     """One whole encode (all K steps, every launch, the fork / join of the internal streams) captured ONCE as a
     hipGraph and replayed per batch -- for callers that encode many batches of one shape (a training loop, a
     streaming encoder).  mp_encode_f32 is capture-safe (no host synchronisation, caller-supplied workspace), so
-    the capture is the ordinary call under torch.cuda.graph.  Measured (scripts/graph_latency.py): 1.18x at
-    BASELINE configs[0] (one segment, 8 steps: 227 -> 192 us), 1.03x at the headline shape.
+    the capture is the ordinary call under torch.cuda.graph.  Measured (scripts/graph_latency.py,
+    scripts/graph_groups.py): 1.15x at BASELINE configs[0] (one segment, 8 steps: 226 -> 198 us); at the headline
+    shape a replay (848 k segment-iterations/s) beats the one-stream schedule (819 k) but not the plain launches of
+    the four-sub-batch default (877 k): a graph's parallel branches run on the runtime's own streams, which share
+    hardware queues beyond two -- so a plan is captured with two sub-batches.
 
         plan = EncodePlan(B, N, dict_unit, n_steps)        # captures; the dictionary is read at replay time
         atom, lag, gain, residual = plan(signal)             # [B, N] -> views of the plan's static outputs
@@ -251,7 +254,7 @@ class EncodePlan:
     The outputs are overwritten by the next call (clone what must outlive it).  As with encode(), a segment
     whose FFT screen overflowed is marked with gain = NaN: encode_checked() is the checked, un-captured form."""
 
-    def __init__(self, batch, n_samples, dict_unit, n_steps, path=None, flags=0, want_residual=True):
+    def __init__(self, batch, n_samples, dict_unit, n_steps, path=None, flags=0, want_residual=True, sub_batches=2):
         dict_unit = _f32(dict_unit)
         _require_cuda(dict_unit)
         self.path = default_path(dict_unit.shape[1]) if path is None else path
@@ -259,6 +262,13 @@ class EncodePlan:
         dev = dict_unit.device
         self.signal = torch.zeros((int(batch), int(n_samples)), dtype=torch.float32, device=dev)
         args = dict(path=self.path, flags=flags, want_residual=want_residual)
+        tune(MP_TUNE_GROUPS, max(2, min(4, int(sub_batches))))  # (process-wide knob, restored below: see the docstring)
+        try:
+            self._capture(dev, n_steps, args)
+        finally:
+            tune(MP_TUNE_GROUPS, 4)
+
+    def _capture(self, dev, n_steps, args):
         side = torch.cuda.Stream(dev)
         side.wait_stream(torch.cuda.current_stream(dev))
         with torch.cuda.stream(side):  # warm-up outside the capture: kernel attributes, the stream pool
