@@ -36,7 +36,9 @@ import ctypes
 nat.lib().mp_stream_pair_ratio.restype = ctypes.c_float
 nat.lib().mp_stream_pair_ratio.argtypes = [ctypes.c_int, ctypes.c_int]
 print("spin ratio of internal stream pairs (1 = side by side, 2 = one after the other):",
-      {f"{a}{b}": round(float(nat.lib().mp_stream_pair_ratio(a, b)), 2) for a, b in ((0, 1), (0, 2), (0, 3), (1, 2), (1, 3), (2, 3))})
+      {f"s{a}{b}": round(float(nat.lib().mp_stream_pair_ratio(a, b)), 2) for a, b in ((0, 1), (0, 2), (0, 3), (1, 2), (1, 3), (2, 3))})
+if "ratios-only" in sys.argv:
+    sys.exit(0)
 print("default (two sub-batches)", rate(0), " one stream", rate(nat.MP_FLAG_NO_OVERLAP), flush=True)
 for g in (3, 4, 2):
     nat.tune(nat.MP_TUNE_GROUPS, g)

@@ -125,3 +125,17 @@ def test_rccl_backend_initialises_and_runs_the_collectives_used():
     out = subprocess.run([sys.executable, os.path.join(REPO, "scripts", "rccl_single_rank_check.py")], env=env,
                          capture_output=True, text=True, timeout=300)
     assert out.returncode == 0 and "rccl ok" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
+
+
+def test_internal_streams_run_side_by_side_even_when_created_after_a_graph_capture():
+    """The sub-batch streams are chosen by a spin test (stream_pool): in a fresh process that captured a hipGraph
+    before the library created its streams -- the order that used to put the first two on one hardware queue and
+    made the default schedule 30 % slower than one stream -- every pair of the kept streams overlaps."""
+    import ast
+    import subprocess
+    out = subprocess.run([sys.executable, os.path.join(REPO, "scripts", "after_capture.py"), "torch-graph-first",
+                          "ratios-only"], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    line = [l for l in out.stdout.splitlines() if l.startswith("spin ratio")][0]
+    ratios = ast.literal_eval(line[line.index("{"):])
+    assert len(ratios) == 6 and all(0.5 < r < 1.5 for r in ratios.values()), ratios
