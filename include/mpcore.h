@@ -162,6 +162,14 @@ int mp_feature_map_f32(const float *residual, int64_t B, int64_t N, const float 
                        void *stream);
 
 /*
+ * Test / diagnosis hook.  mp_encode_f32 runs sub-batches on internal streams that a spin test at their creation
+ * showed running kernels side by side (streams multiplexed onto one hardware queue would serialise them).  This
+ * repeats the test for internal streams q0, q1 in [0, 4): elapsed(two 40 us spins, one per stream) / elapsed(one
+ * spin) -- about 1 side by side, about 2 one after the other; negative on error.  Synchronises with the host.
+ */
+float mp_stream_pair_ratio(int q0, int q1);
+
+/*
  * Test hook: batched complex FFT of 2^log2_m points (8 <= log2_m <= 14), unscaled -- the transforms
  * MP_PATH_FFT is built on.  inverse = 0: forward, 1: inverse (radix-4 Stockham in LDS: window and
  * dictionary spectra), 2: inverse through the screen's mixed-radix register transform (log2_m >= 10).

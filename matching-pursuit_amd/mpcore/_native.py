@@ -38,6 +38,7 @@ EXPORTS = (
     "mp_feature_map_f32", "mp_scatter_f32", "mp_scatter_rows_f32", "mp_gather_sum_f32",
     "mp_profile_enable", "mp_profile_read", "mp_fft_c2c_f32", "mp_encode_conv_f32", "mp_tune",
     "mp_dictionary_update_f32", "mp_lcn_workspace_bytes", "mp_encode_lcn_f32", "mp_conv_model_backward_f32",
+    "mp_stream_pair_ratio",
 )
 
 _lib = None
