@@ -456,3 +456,38 @@ def test_long_atom_split_transforms_planted_events_and_extreme_amplitudes(oracle
         ref = nat.encode(xd, dd, 4, path=nat.MP_PATH_INCREMENTAL, conv_model=True)
         out = nat.encode(xd, dd, 4, path=nat.MP_PATH_FFT, conv_model=True)
         assert all(torch.equal(a, b) for a, b in zip(out, ref))
+
+
+def test_two_host_threads_encode_concurrently(oracle):
+    """The header promises re-entrancy per stream (thread-local error string, stream pool and launch state; no
+    other mutable globals outside the opt-in profiler): two host threads, each on its own torch stream, encode
+    different batches at the same time (ctypes releases the GIL during the call) and get what a lone call gets."""
+    import threading
+    d = synth.make_dictionary(40, 96, seed=51)
+    du_np = oracle.unit_norm(d)
+    du = torch.from_numpy(du_np).to(DEV)
+    xs = [synth.make_segments(50, 3000, d, n_events=10, seed=52 + i) for i in range(2)]
+    want = [oracle.encode(x, du_np, 6) for x in xs]
+    got = [None, None]
+    errors = []
+
+    def work(i):
+        try:
+            stream = torch.cuda.Stream(DEV)
+            xd = torch.from_numpy(xs[i]).to(DEV)
+            stream.wait_stream(torch.cuda.current_stream(DEV))
+            with torch.cuda.stream(stream):
+                for _ in range(4):
+                    out = nat.encode(xd, du, 6, path=nat.MP_PATH_FFT)   # 50 segments: sub-batches on forked streams
+                stream.synchronize()
+            got[i] = [t.cpu().numpy() for t in out]
+        except Exception as e:  # noqa: BLE001
+            errors.append(repr(e))
+
+    threads = [threading.Thread(target=work, args=(i,)) for i in range(2)]
+    [t.start() for t in threads]
+    [t.join() for t in threads]
+    assert not errors, errors
+    for i in range(2):
+        assert np.array_equal(got[i][0], want[i]["atom"]) and np.array_equal(got[i][1], want[i]["lag"])
+        assert np.array_equal(got[i][2], want[i]["gain"]) and np.array_equal(got[i][3], want[i]["residual"])
