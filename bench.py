@@ -14,8 +14,8 @@ barrier+synchronize pairs, max over ranks, on the library's default kernels (MP_
 screen + exact refinement; events bit-identical to the direct paths, re-checked every run) with the
 batch kept on ONE stream (MP_FLAG_NO_OVERLAP), so that the event-timed kernel durations are not
 stretched by a second sub-batch; `variants` carries the library's own default (four sub-batches on
-forked streams, a few percent faster) and the two direct-correlation (MFMA) schedules with their own
-rooflines.  `roofline` is for the dominant kernel from HIP events recorded inside the timed region on
+forked streams, a few percent faster), its replay from a captured hipGraph (mpcore.EncodePlan) and the two
+direct-correlation (MFMA) schedules with their own rooflines.  `roofline` is for the dominant kernel from HIP events recorded inside the timed region on
 the launch stream (sampled: every 16th iteration, see launch_times); `cpu_baseline` is the CPU oracle
 timed on this host (rank 0, N = 1 only).
 """
