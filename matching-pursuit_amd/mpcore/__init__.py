@@ -7,3 +7,4 @@ from .matchingpursuit import (  # noqa: F401
     EventList, encode_packed, sparse_feature_map_coo)
 from .iterative import iterative_loss, sort_channels_descending_norm  # noqa: F401
 from .streaming import encode_streaming, decode_streaming, StreamCode  # noqa: F401
+from .overlay import install, uninstall  # noqa: F401  (drop-in overlay over the reference's `modules` package)

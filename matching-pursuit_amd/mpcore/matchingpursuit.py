@@ -40,7 +40,7 @@ def _compute_device(t):
 
 def unit_norm(x, dim=-1, epsilon=1e-8):
     """modules/normalization.py:4-6.  2-D fp32 along the last axis runs in mp_unit_norm_f32."""
-    if x.dim() == 2 and dim in (-1, 1) and not x.requires_grad:
+    if x.dim() == 2 and dim in (-1, 1) and x.dtype == torch.float32 and not x.requires_grad:
         dev = _compute_device(x)
         return _native.unit_norm(x.to(dev), epsilon).to(x.device)
     n = torch.norm(x, dim=dim, keepdim=True)

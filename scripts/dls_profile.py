@@ -3,7 +3,7 @@ device time per kernel (the encode's screen / select kernels and the fused dicti
 import os, sys, time
 import numpy as np, torch
 sys.path.insert(0, "matching-pursuit_amd")
-import modules.matchingpursuit as mp
+from mpcore import matchingpursuit as mp
 from mpcore import synth
 from torch.profiler import profile, ProfilerActivity
 A, L, N, B, K = 512, 512, 32768, 64, 64

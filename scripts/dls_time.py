@@ -4,7 +4,7 @@ import os, sys, time
 import numpy as np, torch
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(REPO, "matching-pursuit_amd"))
-import modules.matchingpursuit as mp
+from mpcore import matchingpursuit as mp
 from mpcore import synth
 A, L, N, B, K = 512, 512, 32768, 64, 64
 dn = synth.make_dictionary(A, L, seed=1000)

@@ -11,6 +11,13 @@ for p in (PKG, REPO):
 
 GOLDEN = os.path.join(REPO, "tests", "golden")
 
+# The reference's names (`modules.matchingpursuit.sparse_code`, ...) as the tests use them.  No reference
+# checkout is on sys.path here or on the GPU box, so this registers mpcore's stand-alone `modules` package
+# (mpcore/overlay.py); the overlay over the REAL package is exercised by tests/test_overlay.py in a subprocess.
+import mpcore  # noqa: E402
+
+assert mpcore.install(multiband=True) == "standalone"
+
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
