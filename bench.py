@@ -15,13 +15,23 @@ screen + exact refinement; events bit-identical to the direct paths, re-checked 
 batch kept on ONE stream (MP_FLAG_NO_OVERLAP), so that the event-timed kernel durations are not
 stretched by a second sub-batch; `variants` carries the library's own default (four sub-batches on
 forked streams, a few percent faster), its replay from a captured hipGraph (mpcore.EncodePlan) and the two
-direct-correlation (MFMA) schedules with their own rooflines.  `roofline` is for the dominant kernel from HIP events recorded inside the timed region on
-the launch stream (sampled: every 16th iteration, see launch_times); `cpu_baseline` is the CPU oracle
-timed on this host (rank 0, N = 1 only).
+direct-correlation (MFMA) schedules with their own rooflines.  `roofline` is for the dominant kernel from HIP
+events recorded inside the timed region on the launch stream (sampled: every 16th iteration, see launch_times).
+For the FFT schedule the bound is packed-fp32 VALU issue, NOT HBM: the screen's spectra are L2 / Infinity-Cache
+resident, and the measured fabric traffic (`traffic`, from the committed PMC passes) over the kernel time is
+reported beside it as `hbm_gbs_measured` / `frac_hbm`.  `cpu_baseline` is the CPU oracle timed on this host
+(rank 0, N = 1 only).
+
+`python bench.py --gpus N` with N > 1 and no WORLD_SIZE in the environment starts its own N ranks
+(`python -m torch.distributed.run --nproc-per-node N bench.py ...` as a child process, before anything touches the
+GPU), relays rank 0's JSON line and exits with the child's status; started by torch.distributed.run itself it is
+one of the ranks.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -38,6 +48,11 @@ from mpcore import synth  # noqa: E402
 A, L, N, B_PER_GPU, K_ITERS = 512, 512, 32768, 64, 64
 PEAK_MFMA_F32_TFLOPS = 157.3  # MI355X dense fp32 matrix peak (MI355X_MICROARCH.md)
 PEAK_HBM_GBS = 8000.0         # MI355X HBM3E peak (MI355X_MICROARCH.md)
+# packed-fp32 VALU issue: 256 CUs x 4 SIMDs, 2.4 GHz, one wave64 v_pk_{fma,mul,add}_f32 per 4 cycles and SIMD
+# (= 64 flop / clk / SIMD, the 157.3 TFLOP/s vector peak of MI355X_MICROARCH.md)
+N_SIMD, PEAK_CLOCK_HZ, CYCLES_PER_WAVE_INSTR = 1024, 2.4e9, 4
+PEAK_VALU_GINSTR = N_SIMD * PEAK_CLOCK_HZ / CYCLES_PER_WAVE_INSTR / 1e9   # 614.4 G wave-instructions/s
+VALU_PER_THREAD_TRANSFORM = 410  # VALU instructions of one 16-point thread-transform of the screen (counted in the ISA)
 PATHS = {"fft": nat.MP_PATH_FFT, "incremental": nat.MP_PATH_INCREMENTAL, "direct": nat.MP_PATH_DIRECT}
 
 
@@ -147,38 +162,52 @@ def launch_times(prof, steps):
 
 
 def roofline_fft(prof, n_segments, steps):
-    """HBM-style roofline of fft_screen_kernel: algorithmic bytes (above) / launch durations."""
+    """Roofline of fft_screen_kernel on the resource that binds it: packed-fp32 VALU issue.
+
+    achieved = ALGORITHMIC wave-instructions (transforms x waves per transform x 410 VALU instructions per
+    16-point thread-transform, counted in the ISA; rocprof's SQ_INSTS_VALU for an incremental launch is 9 % above
+    this count: address arithmetic and the cell-maximum epilogue) / launch durations; peak = 1024 SIMDs x 2.4 GHz / 4
+    cycles per wave64 instruction.  HBM is reported beside it from the committed PMC passes: `traffic` bytes per
+    launch / average launch duration = hbm_gbs_measured."""
     lt = launch_times(prof, steps)
     if lt is None:
         return None
     sec, per_kind = lt
-    total, full, inc = algorithmic_bytes_fft(n_segments, K_ITERS)
-    achieved = total * steps / sec / 1e9
     M, V = fft_geometry()
-    survey_bytes = (8.0 * ((N + L) // 2 + 1) * (A + 1) + 8.0 * N) * n_segments * K_ITERS  # SURVEY.md 8(d)
+    transforms = n_segments * (A // 2) * (-(-N // V) + K_ITERS - 1) * steps
+    wave_instr = transforms * (M // 16 // 64) * VALU_PER_THREAD_TRANSFORM
+    achieved = wave_instr / sec / 1e9
+    traffic = pmc_traffic("fft_screen")
     out = {
-        "bound": "hbm", "achieved": round(achieved, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
-        "frac": round(achieved / PEAK_HBM_GBS, 4), "traffic": pmc_traffic("fft_screen"),
+        "bound": "valu", "achieved": round(achieved, 1), "peak": round(PEAK_VALU_GINSTR, 1),
+        "unit": "G wave64-instructions/s (packed fp32 issue)",
+        "frac": round(achieved / PEAK_VALU_GINSTR, 4), "traffic": traffic,
         "kernel": "fft_screen_kernel<11> (radix-16 Stockham, packed fp32)",
     }
     out.update(per_kind)
+    avg_s = sec / per_kind["launches"]
+    if traffic is not None:
+        out["hbm_gbs_measured"] = round(traffic / avg_s / 1e9, 1)
+        out["frac_hbm"] = round(traffic / avg_s / 1e9 / PEAK_HBM_GBS, 4)
+    total, full, inc = algorithmic_bytes_fft(n_segments, K_ITERS)
+    survey_bytes = (8.0 * ((N + L) // 2 + 1) * (A + 1) + 8.0 * N) * n_segments * K_ITERS  # SURVEY.md 8(d)
     out.update({
         "other_kernels_avg_ms_per_iteration": round(prof["select"][0] / max(per_kind["timed_with_events"]["full_pass"]
                                                     + per_kind["timed_with_events"]["incremental"], 1), 5),
-        "algorithmic_mb_per_launch": round(total * steps / per_kind["launches"] / 1e6, 2),
-        "note": "algorithmic bytes = spectra the kernel's own algorithm streams (mostly L2/Infinity-Cache "
-                "hits: the 4 MiB of pair spectra are shared by all segments); the kernel is packed-fp32 "
-                "VALU / LDS limited, see DESIGN.md",
+        "algorithmic_wave_instructions_per_launch": round(wave_instr / per_kind["launches"]),
+        "transforms": transforms,
+        "valu_floor_ms_per_launch": round(wave_instr / (PEAK_VALU_GINSTR * 1e9) * 1e3 / per_kind["launches"], 5),
+        "spectra_streamed_mb_per_launch": round(total * steps / per_kind["launches"] / 1e6, 2),
+        "spectra_streamed_gbs": round(total * steps / sec / 1e9, 1),
         "survey_8d_equivalent_gbs": round(survey_bytes * steps / sec / 1e9, 1),
+        "note": "HBM does not bind this kernel and the north-star's >= 70 % HBM target does not apply to it: the "
+                "spectra it streams (spectra_streamed_*) are L2 / Infinity-Cache hits (4 MiB of pair spectra shared "
+                "by all segments); fabric traffic is `traffic` bytes per launch (FETCH_SIZE x 2 + WRITE_SIZE, "
+                "separate rocprofv3 --pmc passes, profiles/) = hbm_gbs_measured.  By SURVEY.md 8(d)'s own per-unit "
+                "bytes (the reference's full-length transform) the run would exceed HBM peak "
+                "(survey_8d_equivalent_gbs): the screen does not do that work, it screens one window of dirty lags "
+                "and refines exactly (DESIGN.md 4b, 6).",
     })
-    # the resource that actually binds the kernel: packed-fp32 VALU issue.  ~410 VALU instructions per
-    # 16-point thread-transform (353 of them v_pk_{add,mul,fma}_f32; counted in the ISA), M / 16 threads per
-    # transform, 4 issue cycles per wave64 instruction, 1024 SIMDs at the 2.4 GHz peak clock
-    transforms = n_segments * (A // 2) * (-(-N // V) + K_ITERS - 1) * steps
-    valu_floor_s = transforms * (M // 16 // 64) * 410 * 4 / (1024 * 2.4e9)
-    out["valu_issue"] = {"transforms": transforms, "floor_ms_per_launch": round(valu_floor_s * 1e3 / per_kind["launches"], 5),
-                         "frac_of_measured": round(valu_floor_s / sec, 4),
-                         "note": "time the VALU instructions alone need at 2.4 GHz / measured kernel time"}
     return out
 
 
@@ -235,6 +264,52 @@ def cpu_baseline(d, x_host, gpu_sample):
     }, parity
 
 
+def _free_port():
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        return sock.getsockname()[1]
+
+
+def launch_ranks(n, argv):
+    """`python bench.py --gpus N` outside torch.distributed.run: start the N ranks as ONE child process tree
+    (this process has not touched the GPU and never will), relay rank 0's JSON line, return the child's status."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)] + list(argv)
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: RCCL across processes needs it on this driver
+    proc = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    lines = proc.stdout.splitlines()
+    json_lines = [ln for ln in lines if ln.lstrip().startswith("{")]
+    for ln in lines:
+        if ln not in json_lines:
+            print(ln, file=sys.stderr)
+    if proc.returncode != 0:
+        print(f"bench.py: a rank failed (torch.distributed.run exit code {proc.returncode})", file=sys.stderr)
+        return proc.returncode
+    if len(json_lines) != 1:
+        print(f"bench.py: expected one JSON line from rank 0, got {len(json_lines)}", file=sys.stderr)
+        return 1
+    print(json_lines[0], flush=True)
+    return 0
+
+
+def dry_run(args):
+    """Launcher / rendezvous rehearsal without a GPU (tests/test_distributed_cpu.py): the ranks meet on gloo, go
+    through the bench's barrier and max-over-ranks reduction, rank 0 prints one line.  Measures nothing."""
+    rank, world, _ = mpdist.init_from_env(backend=args.backend or "gloo")
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    mpdist.barrier(None)
+    t = mpdist.all_reduce_max(torch.tensor([1.0 + rank], dtype=torch.float64), None)
+    lo, hi = mpdist.shard_range(world * B_PER_GPU, rank, world)
+    n = mpdist.all_reduce_sum(torch.tensor([float(hi - lo)], dtype=torch.float64), None)
+    if rank == 0:
+        print(json.dumps({"dry_run": True, "value": None, "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                          "max_over_ranks": float(t.item()), "segments_all_ranks": int(n.item())}), flush=True)
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -251,7 +326,15 @@ def main():
     ap.add_argument("--backend", default=None, help="torch.distributed backend (default nccl = RCCL)")
     ap.add_argument("--share-device", action="store_true",
                     help="rehearsal only: every rank uses cuda:0 (with --backend gloo on a one-GPU box)")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="launcher / rendezvous rehearsal on CPU: no encode, nothing measured")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # not under torch.distributed.run: become the launcher.  Nothing above has initialised the GPU (imports only).
+        sys.exit(launch_ranks(args.gpus, sys.argv[1:]))
+    if args.dry_run:
+        return dry_run(args)
 
     if args.share_device:
         os.environ["LOCAL_RANK"] = "0"

@@ -98,3 +98,32 @@ def test_grouping_matches_reference_flatten_order(golden_dir):
         got = torch.stack([atom.reshape(-1)[perm], perm // K, lag.reshape(-1)[perm]], dim=1).numpy()
         assert np.array_equal(got, z["flat_order"])
         assert sum(counts) == B * K
+
+
+def _bench(*argv):
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    return subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), *argv], capture_output=True, text=True,
+                          env=env, timeout=600)
+
+
+def test_bench_launches_its_own_ranks_when_started_plainly():
+    """`python bench.py --gpus 2` with no WORLD_SIZE in the environment (how the driver starts it) must start
+    the two ranks itself and relay exactly one JSON line from rank 0 (--dry-run: gloo on CPU, no encode)."""
+    import json
+    out = _bench("--gpus", "2", "--dry-run", "--steps", "3", "--warmup", "1")
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, out.stdout
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["steps"] == 3 and line["warmup"] == 1
+    assert line["max_over_ranks"] == 2.0            # the max over ranks of (1 + rank)
+    assert line["segments_all_ranks"] == 128        # 64 segments per rank, weak scaling
+
+
+@pytest.mark.skipif(torch.cuda.is_available(), reason="uses the no-GPU failure of a rank")
+def test_bench_launcher_exits_nonzero_when_a_rank_fails():
+    out = _bench("--gpus", "2", "--steps", "1", "--warmup", "0", "--no-cpu", "--no-variants")
+    assert out.returncode != 0
+    assert out.stdout.strip() == ""                 # no JSON line from a failed job
+    assert "needs a GPU" in out.stderr
