@@ -14,8 +14,9 @@
  *   sparse_code loop           modules/matchingpursuit.py:269-328
  *   scatter_segments (decode)  modules/matchingpursuit.py:20-58
  *   dictionary_learning_step   modules/matchingpursuit.py:348-419
- *   sparse_feature_map         modules/matchingpursuit.py:68-125
  *   local contrast norm        modules/matchingpursuit.py:284-294  (mpo_encode_lcn)
+ * (sparse_feature_map :68-125, sparse_coding_loss :128-146 and the approximate branches of
+ *  modules/conv.py:24-47 are restated in numpy on top of these, in oracle/mp_oracle.py.)
  *
  * Arithmetic contract (this is what the HIP kernels are held to, bit for bit):
  *   - fm[a,t] is ONE fp32 fused-multiply-add chain in ascending k:

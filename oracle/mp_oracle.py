@@ -174,6 +174,64 @@ def dictionary_learning_step(signal, d_raw, n_steps):
 
 
 # ----------------------------------------------------------------------------------------------
+# numpy restatements on top of the C loop (small inputs only)
+# ----------------------------------------------------------------------------------------------
+def sparse_feature_map(signal, d_raw, n_steps):
+    """modules/matchingpursuit.py:68-125, forward values: the loop is sparse_code's (direct correlation :88-91,
+    signed first-max argmax :103, cropped subtraction :115-120) and `fm += soft_dirac(f) * f` (:100-101) adds the
+    map's value at the argmax, soft_dirac's forward being the argmax's one-hot (modules/sparse.py:29-43).
+    -> (fm [B, A, N] float32, residual [B, N])."""
+    s = np.ascontiguousarray(signal, dtype=np.float32).reshape(len(signal), -1)
+    du = unit_norm(d_raw)                                                   # :80
+    out = encode(s, du, n_steps)
+    B, N = s.shape
+    fm = np.zeros((B, du.shape[0], N), dtype=np.float32)
+    for k in range(int(n_steps)):                                           # one float32 add per step, as :101
+        fm[np.arange(B), out["atom"][:, k], out["lag"][:, k]] += out["gain"][:, k]
+    return fm, out["residual"]
+
+
+def sparse_coding_loss(recon, target, d_raw, n_steps):
+    """modules/matchingpursuit.py:128-146: binary cross entropy (mean over all B*A*N cells, logs clamped at
+    -100 as torch.nn.functional.binary_cross_entropy does) between the two maps divided by their joint maximum."""
+    r_map, _ = sparse_feature_map(recon, d_raw, n_steps)
+    t_map, _ = sparse_feature_map(target, d_raw, n_steps)
+    mx = max(float(r_map.max()), float(t_map.max()))                        # :139-141
+    r = (r_map / np.float32(mx)).astype(np.float64)
+    t = (t_map / np.float32(mx)).astype(np.float64)
+    with np.errstate(divide="ignore"):
+        log_r = np.maximum(np.log(r), -100.0)
+        log_1r = np.maximum(np.log1p(-r), -100.0)
+    return float(-(t * log_r + (1.0 - t) * log_1r).mean())
+
+
+def fft_convolve(signal, dict_unit, approx=None):
+    """modules/conv.py:11-53 with numpy's FFT (float64 inside): signal [B, 1, N] -> fm [B, A, N].
+    approx=slice keeps the slice's bins (:24-29); approx=int < N keeps, per segment, the `approx` largest-magnitude
+    bins of the SIGNAL spectrum -- and, the index tensor being [B, 1, k], only atom 0's row of the product is ever
+    filled (:30-47: gather and scatter both follow the index's shape); anything else is the exact map (:48-49)."""
+    s = np.asarray(signal, dtype=np.float64)
+    d = np.asarray(dict_unit, dtype=np.float64)
+    B, _, N = s.shape
+    A, L = d.shape
+    M = N + L
+    sig = np.fft.rfft(np.pad(s, ((0, 0), (0, 0), (0, L))), axis=-1)         # [B, 1, F]
+    atom = np.fft.rfft(np.pad(d, ((0, 0), (0, M - L)))[:, ::-1], axis=-1)[None]  # [1, A, F]
+    if isinstance(approx, slice):
+        spec = np.zeros((B, A, sig.shape[-1]), dtype=np.complex128)
+        spec[..., approx] = sig[..., approx] * atom[..., approx]
+    elif isinstance(approx, int) and approx < N:
+        spec = np.zeros((B, A, sig.shape[-1]), dtype=np.complex128)
+        idx = np.argsort(-np.abs(sig[:, 0, :]), axis=-1, kind="stable")[:, :approx]     # [B, k]
+        rows = np.arange(B)[:, None]
+        spec[rows, 0, idx] = sig[rows, 0, idx] * atom[0, 0, idx]
+    else:
+        spec = sig * atom
+    fm = np.roll(np.fft.irfft(spec, n=M, axis=-1), 1, axis=-1)
+    return fm[..., :N].astype(np.float32)
+
+
+# ----------------------------------------------------------------------------------------------
 # float64 arbiter (pure numpy; small inputs only)
 # ----------------------------------------------------------------------------------------------
 def arbiter_feature_map(residual, dict_unit):

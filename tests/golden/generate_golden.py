@@ -311,6 +311,7 @@ def main():
 
     lcn_fixtures(mp, norm)
     key_point_gradients(mp)
+    loss_and_approx_fixtures(mp, conv, norm)
 
     print("fixture report (name, min relative top-2 gap, residual dB, direct==fft picks):")
     for r in report:
@@ -388,8 +389,74 @@ def key_point_gradients(mp):
           float(xt.grad.abs().max()))
 
 
+def loss_and_approx_fixtures(mp, conv, norm):
+    """sparse_coding_loss (:128-146) and SparseCodingLoss.loss (:422-463) values and gradients; the approximate
+    correlation branches of fft_convolve (conv.py:24-47) and the picks sparse_code makes on them."""
+    # --- sparse_coding_loss: value and d loss / d recon.  recon = target with two planted events replaced, so the
+    # two maps share some cells and differ in others (a cell present in one map only costs 100 * value, the clamp of
+    # binary_cross_entropy's log)
+    A, L, N, B, K = 16, 64, 1024, 2, 6
+    d = synth.make_dictionary(A, L, seed=1515)
+    target = synth.make_segments(B, N, d, n_events=6, seed=1515)
+    other = synth.make_segments(B, N, d, n_events=6, seed=1516)
+    recon = (0.55 * target + 0.45 * other).astype(np.float32)
+    dt = torch.from_numpy(d)
+    rt = torch.from_numpy(recon.copy()).requires_grad_(True)
+    loss = mp.sparse_coding_loss(rt, torch.from_numpy(target), dt, n_steps=K)
+    loss.backward()
+    with torch.no_grad():
+        r_map = mp.sparse_feature_map(torch.from_numpy(recon), dt, n_steps=K)
+        t_map = mp.sparse_feature_map(torch.from_numpy(target), dt, n_steps=K)
+    shared = int(((r_map != 0) & (t_map != 0)).sum())
+    # --- SparseCodingLoss with one learning step: the dictionary after the step (dictionary_learning_step on the
+    # TARGET, :441-451), the loss of that call and of the next one (no further step)
+    mod = mp.SparseCodingLoss(A, L, n_steps=K, approx=None, learning_steps=1)
+    mod.d = norm.unit_norm(dt.clone())          # the constructor draws from torch's RNG: pin the dictionary
+    import io
+    from contextlib import redirect_stdout
+    with redirect_stdout(io.StringIO()):          # ('LEARNING STEP 1', :451)
+        # (3-D [B, 1, N]: the learning step unpacks batch, channels, time, :358)
+        l1 = mod.loss(torch.from_numpy(recon)[:, None, :], torch.from_numpy(target)[:, None, :])
+    d_after = mod.d.detach().numpy().copy()
+    l2 = mod.loss(torch.from_numpy(recon)[:, None, :], torch.from_numpy(target)[:, None, :])
+    assert mod._steps_executed == 1
+    np.savez_compressed(os.path.join(HERE, "sparse_coding_loss.npz"), d_raw=d, target=target, recon=recon,
+                        n_steps=np.int64(K), loss=np.float64(loss.item()), grad_recon=rt.grad.numpy(),
+                        r_nz=torch.nonzero(r_map).numpy(), t_nz=torch.nonzero(t_map).numpy(),
+                        loss_after_learning_step=np.float64(l1.item()), d_after_learning_step=d_after,
+                        loss_second_call=np.float64(l2.item()))
+    print("  sparse_coding_loss", float(loss.item()), "shared cells", shared, "| SparseCodingLoss", float(l1.item()),
+          float(l2.item()))
+
+    # --- approximate correlation: the maps themselves, and sparse_code's picks on them with their top-2 gaps
+    A, L, N, B, K = 24, 64, 1024, 2, 8
+    d = synth.make_dictionary(A, L, seed=1616)
+    x = synth.make_segments(B, N, d, n_events=8, seed=1616)
+    sig = torch.from_numpy(x)[:, None, :]
+    du = norm.unit_norm(torch.from_numpy(d))
+    slce = slice(8, 200)                          # bins of the (N + L)-point transform, conv.py:24-29
+    topk = 96                                     # conv.py:30-47
+    out = dict(signal=x, d_raw=d, slice_start=np.int64(slce.start), slice_stop=np.int64(slce.stop),
+               topk=np.int64(topk), n_steps=np.int64(K))
+    with torch.no_grad():
+        out["fm_slice"] = conv.fft_convolve(sig, du, approx=slce).numpy()
+        out["fm_topk"] = conv.fft_convolve(sig, du, approx=topk).numpy()
+    for tag, approx in (("slice", slce), ("topk", topk)):
+        enc = run_encode(mp, sig, torch.from_numpy(d), K, approx=approx)
+        gap = (enc["top2"][..., 0] - enc["top2"][..., 1]) / np.abs(enc["top2"][..., 0])
+        for k in ("atom", "lag", "gain", "top2", "residual"):
+            out[f"{tag}_{k}"] = enc[k]
+        print(f"  approx={tag}: min relative top-2 gap {float(gap.min()):.3e}; atoms used {sorted(set(enc['atom'].reshape(-1).tolist()))}")
+    np.savez_compressed(os.path.join(HERE, "approx_correlation.npz"), **out)
+
+
 if __name__ == "__main__":
-    if len(sys.argv) > 1 and sys.argv[1] == "kp":  # only the key-point gradient fixture
+    if len(sys.argv) > 1 and sys.argv[1] == "loss":  # only the loss / approximate-correlation fixtures
+        torch.manual_seed(0)
+        torch.set_num_threads(8)
+        _mp, _conv, _norm, _stft, _ns = load_reference()
+        loss_and_approx_fixtures(_mp, _conv, _norm)
+    elif len(sys.argv) > 1 and sys.argv[1] == "kp":  # only the key-point gradient fixture
         torch.manual_seed(0)
         torch.set_num_threads(8)
         key_point_gradients(load_reference()[0])

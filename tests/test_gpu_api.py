@@ -200,6 +200,88 @@ def test_sparse_feature_map_gradient_matches_reference(golden_dir):
     assert recon.grad is not None and torch.isfinite(recon.grad).all() and recon.grad.abs().sum() > 0
 
 
+def test_sparse_coding_loss_matches_reference(golden_dir):
+    """modules/matchingpursuit.py:128-146 against the reference's own value and d loss / d recon; both the
+    event-built (no gradient) and the dense (gradient) evaluation."""
+    z = np.load(os.path.join(golden_dir, "sparse_coding_loss.npz"))
+    d = torch.from_numpy(z["d_raw"]).to(DEV)
+    target = torch.from_numpy(z["target"]).to(DEV)
+    K = int(z["n_steps"])
+    want = float(z["loss"])
+    with torch.no_grad():
+        coo = mp.sparse_coding_loss(torch.from_numpy(z["recon"]).to(DEV), target, d, n_steps=K)
+    assert abs(coo.item() - want) <= 1e-5 * want
+    recon = torch.from_numpy(z["recon"]).to(DEV).requires_grad_(True)
+    dense = mp.sparse_coding_loss(recon, target, d, n_steps=K)
+    assert abs(dense.item() - want) <= 1e-5 * want
+    dense.backward()
+    g, gw = recon.grad.cpu().numpy(), z["grad_recon"]
+    assert g.shape == gw.shape
+    assert np.abs(g - gw).max() <= 1e-3 * np.abs(gw).max()
+    # the maps behind it: same nonzero cells as the reference's
+    r_map = mp.sparse_feature_map(torch.from_numpy(z["recon"]).to(DEV), d, n_steps=K)
+    assert np.array_equal(torch.nonzero(r_map).cpu().numpy(), z["r_nz"])
+
+
+def test_sparse_coding_loss_module_learning_step_matches_reference(golden_dir):
+    """SparseCodingLoss.loss (:422-463): the first `learning_steps` calls run dictionary_learning_step on the
+    target before evaluating the loss."""
+    z = np.load(os.path.join(golden_dir, "sparse_coding_loss.npz"))
+    A, L = z["d_raw"].shape
+    mod = mp.SparseCodingLoss(A, L, n_steps=int(z["n_steps"]), approx=None, learning_steps=1, device=DEV)
+    assert mod.d.shape == (A, L) and abs(float(torch.norm(mod.d, dim=-1).mean()) - 1) < 1e-5
+    import modules
+    mod.d = modules.unit_norm(torch.from_numpy(z["d_raw"]).to(DEV))   # as the fixture pins it
+    recon = torch.from_numpy(z["recon"]).to(DEV)[:, None, :]
+    target = torch.from_numpy(z["target"]).to(DEV)[:, None, :]
+    l1 = mod.loss(recon, target)
+    assert mod._steps_executed == 1
+    assert np.abs(mod.d.cpu().numpy() - z["d_after_learning_step"]).max() <= 2e-6
+    want = float(z["loss_after_learning_step"])
+    assert abs(l1.item() - want) <= 1e-5 * want
+    l2 = mod.loss(recon, target)
+    assert mod._steps_executed == 1 and abs(l2.item() - float(z["loss_second_call"])) <= 1e-5 * want
+
+
+def test_approximate_correlation_matches_reference(golden_dir):
+    """conv.py:24-47: the band-slice and top-k-bins maps, and sparse_code's picks on them.  The approximate map
+    decides here, so parity is to tolerance and gated on the reference's own top-2 gap (every step of the
+    fixture has a relative gap >= 1.7e-3)."""
+    import modules.conv as conv
+    z = np.load(os.path.join(golden_dir, "approx_correlation.npz"))
+    d = torch.from_numpy(z["d_raw"]).to(DEV)
+    import modules
+    du = modules.unit_norm(d)
+    sig = torch.from_numpy(z["signal"]).to(DEV)[:, None, :]
+    slce = slice(int(z["slice_start"]), int(z["slice_stop"]))
+    topk, K = int(z["topk"]), int(z["n_steps"])
+    fm_s = conv.fft_convolve(sig, du, approx=slce).cpu().numpy()
+    fm_k = conv.fft_convolve(sig, du, approx=topk).cpu().numpy()
+    assert np.abs(fm_s - z["fm_slice"]).max() <= 1e-5 * np.abs(z["fm_slice"]).max()
+    assert np.abs(fm_k - z["fm_topk"]).max() <= 1e-5 * np.abs(z["fm_topk"]).max()
+    assert np.abs(fm_k[:, 1:]).max() == 0 and np.abs(z["fm_topk"][:, 1:]).max() == 0   # atom 0 only, as the reference
+    for tag, approx in (("slice", slce), ("topk", topk)):
+        rec = {"atom": [], "lag": []}
+
+        def visit(fm, ai, p, a):
+            rec["atom"].append(int(ai))
+            rec["lag"].append(int(p))
+
+        events, scatter, residual = mp.sparse_code(sig, d, n_steps=K, flatten=True, return_residual=True,
+                                                   approx=approx, visit_key_point=visit)
+        B = sig.shape[0]
+        atom = np.array(rec["atom"]).reshape(K, B).T
+        lag = np.array(rec["lag"]).reshape(K, B).T
+        top2 = z[f"{tag}_top2"]
+        gap = (top2[..., 0] - top2[..., 1]) / np.abs(top2[..., 0])
+        assert gap.min() >= 1e-4
+        assert np.array_equal(atom, z[f"{tag}_atom"]) and np.array_equal(lag, z[f"{tag}_lag"])
+        assert np.abs(residual[:, 0].cpu().numpy() - z[f"{tag}_residual"]).max() <= 1e-4 * np.abs(z["signal"]).max()
+        # the same picks without a hook (the packed route)
+        ev2, _, res2 = mp.sparse_code(sig, d, n_steps=K, flatten=True, return_residual=True, approx=approx)
+        assert sorted((e[0], e[1], int(e[2])) for e in ev2) == sorted((e[0], e[1], int(e[2])) for e in events)
+
+
 def test_unit_norm_and_conv_wrappers(golden_dir):
     import modules
     import modules.conv as conv

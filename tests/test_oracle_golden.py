@@ -109,3 +109,40 @@ def test_oracle_is_deterministic_across_thread_counts(oracle):
     b = oracle.encode(x, d, 10)
     for k in ("atom", "lag", "gain", "residual"):
         assert np.array_equal(a[k], b[k])
+
+
+def test_oracle_sparse_feature_map_and_loss_match_reference(oracle, golden_dir):
+    """sparse_feature_map (:68-125) cells and values, sparse_coding_loss (:128-146) value."""
+    z = np.load(os.path.join(golden_dir, "sparse_feature_map.npz"))
+    fm, res = oracle.sparse_feature_map(z["signal"], z["d_raw"], int(z["n_steps"]))
+    nz = np.argwhere(fm != 0)
+    assert np.array_equal(nz, z["nz_index"])
+    assert np.abs(fm[nz[:, 0], nz[:, 1], nz[:, 2]] - z["nz_value"]).max() <= REL * np.abs(z["nz_value"]).max()
+    assert np.abs(res - z["residual"]).max() <= REL * np.abs(z["signal"]).max()
+    z = np.load(os.path.join(golden_dir, "sparse_coding_loss.npz"))
+    loss = oracle.sparse_coding_loss(z["recon"], z["target"], z["d_raw"], int(z["n_steps"]))
+    assert abs(loss - float(z["loss"])) <= REL * float(z["loss"])
+    # SparseCodingLoss.loss with one learning step (:441-463): dictionary_learning_step on the target, then the loss
+    d_after = oracle.dictionary_learning_step(z["target"], z["d_raw"], int(z["n_steps"]))
+    assert np.abs(d_after - z["d_after_learning_step"]).max() <= 1e-5
+    loss1 = oracle.sparse_coding_loss(z["recon"], z["target"], d_after, int(z["n_steps"]))
+    assert abs(loss1 - float(z["loss_after_learning_step"])) <= REL * float(z["loss_after_learning_step"])
+
+
+def test_oracle_approximate_correlation_matches_reference(oracle, golden_dir):
+    """conv.py:24-47: band slice and top-k bins (the latter fills atom 0's row only, as the reference does)."""
+    z = np.load(os.path.join(golden_dir, "approx_correlation.npz"))
+    du = oracle.unit_norm(z["d_raw"])
+    sig = z["signal"][:, None, :]
+    fm_s = oracle.fft_convolve(sig, du, slice(int(z["slice_start"]), int(z["slice_stop"])))
+    fm_k = oracle.fft_convolve(sig, du, int(z["topk"]))
+    assert np.abs(fm_s - z["fm_slice"]).max() <= REL * np.abs(z["fm_slice"]).max()
+    assert np.abs(fm_k - z["fm_topk"]).max() <= REL * np.abs(z["fm_topk"]).max()
+    assert np.abs(z["fm_topk"][:, 1:]).max() == 0 and np.abs(fm_k[:, 1:]).max() == 0
+    exact = oracle.fft_convolve(sig, du, None)
+    assert np.abs(exact - oracle.feature_map(z["signal"], du)).max() <= REL * np.abs(exact).max()
+    # the first pick of sparse_code(approx=...) is the argmax of these maps
+    for tag, fm in (("slice", fm_s), ("topk", fm_k)):
+        flat = fm.reshape(fm.shape[0], -1).argmax(-1)
+        assert np.array_equal(flat // fm.shape[-1], z[f"{tag}_atom"][:, 0])
+        assert np.array_equal(flat % fm.shape[-1], z[f"{tag}_lag"][:, 0])
