@@ -12,7 +12,12 @@
  *     nothing is allocated or freed on the caller's behalf (workspace is caller-supplied,
  *     so PyTorch's caching allocator owns all memory);
  *   - every call is asynchronous on `stream` (a hipStream_t passed as void*; NULL = the
- *     null stream) and may be captured into a hipGraph: no host synchronisation inside;
+ *     null stream) and may be captured into a hipGraph: no host synchronisation inside.
+ *     ONE exception, once per host thread and device: the first mp_encode_f32 that splits its
+ *     batch over internal streams builds and tests that stream pool (a few ms, synchronises
+ *     with the host) -- unless the call is being captured, in which case it stays on one
+ *     stream instead.  mp_init_streams() does that step explicitly, ahead of time;
+ *     mp_profile_read / mp_audit_read (measurement, debug) synchronise by definition;
  *   - return value: 0 = ok, negative = error; mp_last_error() (thread-local) says why;
  *   - all floating data is fp32; indices are int64 at the boundary (torch's index type);
  *   - C == 1 (mono) only.
@@ -62,6 +67,8 @@ extern "C" {
 #define MP_FLAG_FFT_NO_QUARTER 8192 /* MP_PATH_FFT: segments of <= 16384 cells through scan+refine / select-B instead
                                        of the one-kernel quarter-cell select (default when the batch is split)    */
 #define MP_FLAG_FFT_QUARTER 16384   /* MP_PATH_FFT: the quarter-cell select also when the batch stays on one stream */
+#define MP_FLAG_GROUPS_SHIFT 20
+#define MP_FLAG_GROUPS(n) (((n) & 7) << MP_FLAG_GROUPS_SHIFT) /* this call: n (2..4) sub-batches where the batch is split */
 #define MP_FLAG_NO_PERSISTENT 8 /* one workgroup per 4 cells instead of machine-sized persistent grid */
 
 int mp_version(void);
@@ -79,12 +86,18 @@ const char *mp_last_error(void);
 int mp_profile_enable(int every);
 
 /* Tuning hook (process-wide; results never depend on it as long as tau stays above the transform error):
- *   MP_TUNE_TAU         the FFT screen's error bound per unit of window norm (default 2e-5)
+ *   MP_TUNE_TAU         the FFT screen's error bound per unit of window norm; 0 (default) = the model
+ *                       tau(L, M) = (1.01 L + 4 log2 M) 2^-24: L 2^-24 bounds the fp32 chain's own rounding
+ *                       rigorously, the log2 M term models the transforms (csrc/mpcore.hip::fft_tau)
  *   MP_TUNE_SCREEN_PPS  atom pairs per transform slot in the screen kernel (0 = heuristic)
- *   MP_TUNE_GROUPS      sub-batches when the batch is split over forked streams (2..4, default 4)     */
+ *   MP_TUNE_GROUPS      process-wide default number of sub-batches when a batch is split over forked
+ *                       streams (2..4, default 4); MP_FLAG_GROUPS(n) sets it for one call only
+ *   MP_TUNE_AUDIT       debug: 1 = after every FFT screen recompute the screened cells exactly and record
+ *                       |screen - exact| / eps (mp_audit_read); as slow as MP_PATH_DIRECT                */
 #define MP_TUNE_TAU 1
 #define MP_TUNE_SCREEN_PPS 2
 #define MP_TUNE_GROUPS 3
+#define MP_TUNE_AUDIT 4
 int mp_tune(int key, double value);
 int mp_profile_read(double *ms, int64_t *count);
 
@@ -168,6 +181,17 @@ int mp_feature_map_f32(const float *residual, int64_t B, int64_t N, const float 
  * spin) -- about 1 side by side, about 2 one after the other; negative on error.  Synchronises with the host.
  */
 float mp_stream_pair_ratio(int q0, int q1);
+
+/* Build and test the calling thread's internal stream pool on the current device now (host-synchronising, a
+ * few ms; idempotent) instead of inside the first sub-batched mp_encode_f32.  Call it before capturing an
+ * encode into a hipGraph if the graph should contain sub-batches.  Returns the number of internal streams seen
+ * to run side by side (>= 1; sub-batches need >= 2), or a negative error (e.g. `stream` is being captured). */
+int mp_init_streams(void *stream);
+
+/* Debug (MP_TUNE_AUDIT): the largest |screen - exact| / eps over all cells audited since the last read, their
+ * number, the same for quarter-cell maxima, and how many exceeded 1 (must be 0).  Synchronises the device;
+ * resets the counters.  Any output pointer may be NULL. */
+int mp_audit_read(float *max_ratio, int64_t *cells, float *max_quarter_ratio, int64_t *over_bound);
 
 /*
  * Test hook: batched complex FFT of 2^log2_m points (8 <= log2_m <= 14), unscaled -- the transforms

@@ -21,6 +21,7 @@
 #include <stdio.h>
 #include <string.h>
 
+#include <atomic>
 #include <mutex>
 #include <vector>
 
@@ -49,32 +50,39 @@ int fail(int code, const char *fmt, const char *detail = "") {
 // ------------------------------------------------------------------------------------------------
 enum { PROF_CORR_FULL = 0, PROF_CORR_INC = 1, PROF_SELECT = 2, PROF_KINDS = 3 };
 struct ProfSpan { hipEvent_t a, b; int kind; };
+// Process-wide span list behind a mutex; whether the CURRENT iteration is sampled is per encoding thread (two host
+// threads may encode at once), and a thread closes only the span it opened.
+std::mutex g_prof_mu;
 struct Profiler {
-    bool on = false;      // armed for the current iteration
-    int every = 0;        // 0 = off, 1 = every iteration, n = iterations k with k % n == 0
-    void arm(int k) { on = every > 0 && k % every == 0; }
-    std::vector<ProfSpan> spans;
+    std::atomic<int> every{0};   // 0 = off, 1 = every iteration, n = iterations k with k % n == 0
+    std::vector<ProfSpan> spans; // guarded by g_prof_mu
     std::vector<hipEvent_t> pool;
-    hipEvent_t get() {
+    static bool &armed() { static thread_local bool on = false; return on; }
+    static hipEvent_t &open_end() { static thread_local hipEvent_t e = nullptr; return e; }
+    void arm(int k) { const int n = every.load(std::memory_order_relaxed); armed() = n > 0 && k % n == 0; }
+    hipEvent_t get() {  // caller holds g_prof_mu
         if (!pool.empty()) { hipEvent_t e = pool.back(); pool.pop_back(); return e; }
         hipEvent_t e = nullptr;
         if (hipEventCreate(&e) != hipSuccess) return nullptr;
         return e;
     }
     void begin(int kind, hipStream_t st) {
-        if (!on) return;
+        open_end() = nullptr;
+        if (!armed()) return;
+        std::lock_guard<std::mutex> lk(g_prof_mu);
         ProfSpan s{get(), get(), kind};
         if (!s.a || !s.b) return;
         (void)hipEventRecord(s.a, st);
         spans.push_back(s);
+        open_end() = s.b;
     }
     void end(hipStream_t st) {
-        if (!on || spans.empty()) return;
-        (void)hipEventRecord(spans.back().b, st);
+        if (!armed() || !open_end()) return;
+        (void)hipEventRecord(open_end(), st);
+        open_end() = nullptr;
     }
 };
 Profiler g_prof;
-std::mutex g_prof_mu;
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -1129,11 +1137,19 @@ size_t lds_bytes(const Geom &g) {
            (size_t)(g.TA + 64) * 16;
 }
 
+constexpr int MAX_DEVICES = 16;
+int current_device() {  // index for the per-device caches below (a device beyond the table shares slot 0: re-set, never wrong)
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MAX_DEVICES) dev = 0;
+    return dev;
+}
+
 template <int TA, bool STORE_FM, bool DMA>
 int launch_correlate_t(const Geom &g, const Workspace &w, const int *dirty, float *fm, hipStream_t st) {
     auto kern = correlate_mfma_kernel<TA, STORE_FM, DMA>;
     const size_t lds = lds_bytes(g);
-    static thread_local size_t configured = 0;
+    static thread_local size_t configured_dev[MAX_DEVICES] = {0};  // the attribute is per device (and set per thread: cheap)
+    size_t &configured = configured_dev[current_device()];
     if (lds > configured) {
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -1148,23 +1164,27 @@ int launch_correlate_t(const Geom &g, const Workspace &w, const int *dirty, floa
     return MP_OK;
 }
 
-int g_num_cus = 0;
 int num_cus() {
-    if (g_num_cus == 0) {
+    static std::atomic<int> cus[MAX_DEVICES];  // zero-initialised; racing first calls compute the same value
+    std::atomic<int> &slot = cus[current_device()];
+    int n = slot.load(std::memory_order_relaxed);
+    if (n == 0) {
         int dev = 0;
         hipDeviceProp_t prop;
         if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
-            g_num_cus = prop.multiProcessorCount;
-        if (g_num_cus <= 0) g_num_cus = 256;
+            n = prop.multiProcessorCount;
+        if (n <= 0) n = 256;
+        slot.store(n, std::memory_order_relaxed);
     }
-    return g_num_cus;
+    return n;
 }
 
 template <int TA, bool DMA>
 int launch_persistent_t(const Geom &g, const Workspace &w, const int *dirty, int stagger, hipStream_t st) {
     auto kern = correlate_persistent_kernel<TA, DMA>;
     const size_t lds = lds_bytes(g);
-    static thread_local size_t configured = 0;
+    static thread_local size_t configured_dev[MAX_DEVICES] = {0};
+    size_t &configured = configured_dev[current_device()];
     if (lds > configured) {
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -1282,11 +1302,31 @@ int fft_lds_attr(K kern, size_t bytes) {
     return MP_OK;
 }
 
-int screen_pps_override = 0;  // tuning hook (mp_tune)
-int overlap_groups = 4;        // sub-batches when the batch is split over forked streams (mp_tune)
-// screen error bound per unit of window norm: measured max |fft - chain| is
-// 6e-7 ||window|| (scripts/screen_error.py), so 2e-5 is a >30x margin; mp_tune(MP_TUNE_TAU, x) overrides
-float FFT_TAU = 2.0e-5f;
+// Tuning hooks (mp_tune): plain process-wide defaults, read with relaxed atomics on the encode path.  The number of
+// sub-batches can also be given per call (MP_FLAG_GROUPS(n)), which is what a caller that wants a particular count
+// while other threads encode should use.
+std::atomic<int> screen_pps_override{0};
+std::atomic<int> overlap_groups{4};   // sub-batches when the batch is split over forked streams
+std::atomic<float> tau_override{0.f}; // > 0: replaces the model below
+std::atomic<int> audit_on{0};         // debug: after every screen recompute the screened cells exactly (mp_audit_read)
+
+// The screen's error bound per unit of window norm.  eps = tau * ||window||_2 * max_a ||d_a||
+// must cover |screen value - fp32 fma chain| at every (atom, lag) of the window:
+//   * the chain's own rounding, RIGOROUSLY: acc_k = (acc_{k-1} + r_k d_k)(1 + delta_k), |delta_k| <= u = 2^-24, so
+//     |chain - exact| <= u sum_k |partial_k| (1 + O(L u)) and |partial_k| <= ||r[t .. t+k]|| ||d[0 .. k]|| <= ||window|| ||d||
+//     (Cauchy-Schwarz): <= L u ||window|| ||d||.  Same-sign atoms on a DC offset get within a small factor of it
+//     (partial sums grow linearly and the roundings share a sign inside a binade); random data stay near sqrt(L) u.
+//   * the three fp32 transforms and the spectrum product, MODELLED: c log2(M) u ||window|| ||d|| -- rounding errors of
+//     a Stockham FFT grow with the number of butterfly levels and are relative to the RMS of the result, itself
+//     <= ||window|| ||d||.  c = 4 puts the largest |screen - exact| ever seen by the audit mode (MP_TUNE_AUDIT;
+//     random, planted, DC-offset / same-sign, transient and 1e-30 / 1e18-amplitude inputs, L = 1 .. 8192) below a
+//     quarter of the bound (tests/test_gpu_parity.py::test_screen_error_bound_audit).
+constexpr float FFT_TAU_C = 4.0f;
+float fft_tau(int64_t L, int logM) {
+    const float o = tau_override.load(std::memory_order_relaxed);
+    if (o > 0.f) return o;
+    return (1.01f * (float)L + FFT_TAU_C * (float)logM) * 5.9604645e-8f;
+}
 
 // once per encode, whole batch, on the caller's stream: twiddles, pair spectra, cleared keys / flags
 int fft_setup(const Geom &g, const Workspace &w, const float *du, int flags, hipStream_t st) {
@@ -1339,6 +1379,7 @@ int fft_iteration(const Geom &g, const Workspace &w, const float *du, int K, int
                   int64_t *out_lag, float *out_gain, const Rule &rule, hipStream_t st) {
     FftGeom f;
     if (!make_fft_geom(g, &f)) return fail(MP_ERR_UNSUPPORTED, "MP_PATH_FFT: atom too long%s");
+    const float tau = fft_tau(g.L, f.logM);
     // split transforms: the four-kernel form between screens (the window kernel makes the next spectrum)
     if (f.split) flags = (flags | MP_FLAG_FFT_UNFUSED) & ~(MP_FLAG_FFT_FUSED | MP_FLAG_FFT_QUARTER);
     const size_t lds = (size_t)(f.split ? f.M / 2 : f.M) * sizeof(cpx);
@@ -1391,19 +1432,19 @@ int fft_iteration(const Geom &g, const Workspace &w, const float *du, int K, int
             int pps = 16 / C::SLOTS;
             const int64_t tasks = (int64_t)nw * g.NAT * g.B;
             while (pps > 1 && tasks * (16 / (C::SLOTS * pps)) < 8 * (int64_t)num_cus()) pps >>= 1;
-            if (screen_pps_override > 0 && 16 % (C::SLOTS * screen_pps_override) == 0) pps = screen_pps_override;
+            if (const int po = screen_pps_override.load(std::memory_order_relaxed); po > 0 && 16 % (C::SLOTS * po) == 0) pps = po;
             const size_t lds_s = ((size_t)C::SLOTS * C::M + C::M / 64 + 64) * sizeof(cpx);
             const bool seg_fast = (size_t)g.NAT * f.NPT * f.M * sizeof(cpx) > (size_t)16 << 20;
             const unsigned gwp = nw * (16 / (C::SLOTS * pps));
             const dim3 grid = seg_fast ? dim3((unsigned)g.B, gwp, g.NAT) : dim3(gwp, g.NAT, (unsigned)g.B);
             if ((rc = fft_lds_attr(fft_screen_split_kernel<SPLIT_LOGH>, lds_s))) return rc;
             hipLaunchKernelGGL(fft_screen_split_kernel<SPLIT_LOGH>, grid, dim3(C::WG), lds_s, st, w.xspec, w.pspec,
-                               w.tw, dirty, w.wnorm, w.keys, w.ceps, g.N, g.A, g.NBLK, g.NAT, f.V, f.NW, FFT_TAU, pps,
+                               w.tw, dirty, w.wnorm, w.keys, w.ceps, g.N, g.A, g.NBLK, g.NAT, f.V, f.NW, tau, pps,
                                (int)seg_fast);
         } else if (f.split) {
             hipLaunchKernelGGL(fft_correlate_split_kernel<SPLIT_LOGH>, dim3(2 * nw, g.NAT, (unsigned)g.B), dim3(256), lds, st,
                                w.xspec, w.pspec, w.tw, dirty, w.wnorm, w.keys, w.ceps, g.N, g.A, g.NBLK, g.NAT, f.V,
-                               f.NW, FFT_TAU);
+                               f.NW, tau);
         } else
         MP_FFT_DISPATCH(f.logM, {
             if (LG >= 10 && !(flags & MP_FLAG_FFT_SIMPLE)) {
@@ -1413,7 +1454,7 @@ int fft_iteration(const Geom &g, const Workspace &w, const float *du, int K, int
                 int pps = 16 / C::SLOTS;
                 const int64_t tasks = (int64_t)nw * g.NAT * g.B;
                 while (pps > 1 && tasks * (16 / (C::SLOTS * pps)) < 8 * (int64_t)num_cus()) pps >>= 1;
-                if (screen_pps_override > 0 && 16 % (C::SLOTS * screen_pps_override) == 0) pps = screen_pps_override;
+                if (const int po = screen_pps_override.load(std::memory_order_relaxed); po > 0 && 16 % (C::SLOTS * po) == 0) pps = po;
                 if (quarter) pps = 4;  // one slot = one quarter of a tile
                 float *subk = quarter ? w.subk : nullptr;
                 const size_t lds_s = ((size_t)C::SLOTS * C::M + C::M / 64 + 64) * sizeof(cpx);
@@ -1423,15 +1464,21 @@ int fft_iteration(const Geom &g, const Workspace &w, const float *du, int K, int
                 const dim3 grid = seg_fast ? dim3((unsigned)g.B, gwp, g.NAT) : dim3(gwp, g.NAT, (unsigned)g.B);
                 if ((rc = fft_lds_attr(fft_screen_kernel<LS>, lds_s))) return rc;
                 hipLaunchKernelGGL(fft_screen_kernel<LS>, grid, dim3(C::WG), lds_s, st, w.xspec, w.pspec, w.tw, dirty,
-                                   w.wnorm, w.keys, w.ceps, g.N, g.A, g.NBLK, g.NAT, f.V, f.NW, FFT_TAU, pps, (int)seg_fast, subk, bsum);
+                                   w.wnorm, w.keys, w.ceps, g.N, g.A, g.NBLK, g.NAT, f.V, f.NW, tau, pps, (int)seg_fast, subk, bsum);
             } else {
                 hipLaunchKernelGGL(fft_correlate_kernel<LG>, dim3(nw, g.NAT, (unsigned)g.B), dim3(256), lds, st,
                                    w.xspec, w.pspec, w.tw, dirty, w.wnorm, w.keys, w.ceps, g.N, g.A, g.NBLK,
-                                   g.NAT, f.V, f.NW, FFT_TAU);
+                                   g.NAT, f.V, f.NW, tau);
             }
         })
         g_prof.end(st);
         HIP_TRY(hipGetLastError());
+        if (audit_on.load(std::memory_order_relaxed)) {  // debug: how much of its bound did that screen use?
+            const float *subk_a = (quarter && !f.split) ? w.subk : nullptr;
+            hipLaunchKernelGGL(fft_audit_kernel, dim3(g.NAT, k == 0 ? g.NBLK : g.MAXC, (unsigned)g.B), dim3(64), 0, st,
+                               w.res, du, dirty, w.keys, w.ceps, subk_a, g.N, g.A, g.L, g.Ns, g.NBLK, g.NAT);
+            HIP_TRY(hipGetLastError());
+        }
         g_prof.begin(PROF_SELECT, st);
         if (quarter) {
             const size_t lds_chain = (size_t)(round_up(g.L, 64) + 128) * sizeof(float);
@@ -1538,37 +1585,42 @@ float stream_pair_ratio(hipStream_t a, hipStream_t b) {
     if (!ok || one <= 0.f) return -1.f;
     return (ta > tb ? ta : tb) / one;
 }
-// One pool per host thread and device, created on first use, never destroyed.
+// One pool per host thread and device, never destroyed; built by mp_init_streams(), or by the first sub-batched
+// encode of the thread on the device when that call is not being captured (host-synchronising, a few ms, once).
 // ROCm multiplexes streams onto a few hardware queues (least-used queue at creation time), and two streams on one
 // queue run their kernels one after the other: sub-batches on such a pair are SLOWER than one stream.  Which
 // streams collide depends on what the process created before -- measured: after any hipGraph capture in the
 // process the first two streams created here shared a queue and the default schedule fell from 840 k to 590 k
 // segment-iterations/s (scripts/after_capture.py).  So the pool is chosen, not assumed: of eight candidates, keep
-// those that a 40 us spin test shows running side by side with every stream already kept (a few ms, once).
-StreamPool *stream_pool(hipStream_t caller) {
-    static thread_local StreamPool pools[16];
-    static thread_local bool ready[16] = {false};
+// those that a 40 us spin test shows running side by side with every stream already kept.
+// The test synchronises with the host, so it never runs under a capture: a capturing caller whose thread has no
+// pool yet gets nullptr and the encode stays on ONE stream (nothing untested is assumed; call mp_init_streams()
+// before capturing to get sub-batches inside the graph).
+StreamPool *stream_pool(hipStream_t caller, bool may_build = true) {
+    static thread_local StreamPool pools[MAX_DEVICES];
+    static thread_local bool ready[MAX_DEVICES] = {false};
     int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return nullptr;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MAX_DEVICES) return nullptr;
     if (!ready[dev]) {
+        if (!may_build) return nullptr;
+        hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+        if (hipStreamIsCapturing(caller, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone) return nullptr;
         StreamPool &p = pools[dev];
         constexpr int NCAND = 8;
         hipStream_t cand[NCAND];
         for (int c = 0; c < NCAND; ++c)
             if (hipStreamCreateWithFlags(&cand[c], hipStreamNonBlocking) != hipSuccess) return nullptr;
-        hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
-        const bool can_test = hipStreamIsCapturing(caller, &cap) == hipSuccess && cap == hipStreamCaptureStatusNone;
         int kept[MAX_GROUPS], n = 0;
         bool used[NCAND] = {false};
         for (int c = 0; c < NCAND && n < MAX_GROUPS; ++c) {
             bool apart = true;
-            for (int k = 0; k < n && apart && can_test; ++k) {
+            for (int k = 0; k < n && apart; ++k) {
                 const float r = stream_pair_ratio(cand[kept[k]], cand[c]);
                 apart = r > 0.f && r < 1.5f;
             }
             if (apart) { kept[n++] = c; used[c] = true; }
         }
-        p.n_concurrent = can_test ? n : 2;  // (created inside a capture: untested, the first two as before)
+        p.n_concurrent = n;
         for (int c = 0, q = n; c < NCAND; ++c) {  // fill the rest of the pool, drop what is left
             if (used[c]) continue;
             if (q < MAX_GROUPS) kept[q++] = c, used[c] = true;
@@ -1626,16 +1678,15 @@ size_t mp_workspace_bytes(int64_t B, int64_t N, int64_t A, int64_t L, int K, int
 }
 
 int mp_tune(int key, double value) {
-    if (key == MP_TUNE_TAU && value > 0.0) { FFT_TAU = (float)value; return MP_OK; }
-    if (key == MP_TUNE_SCREEN_PPS) { screen_pps_override = (int)value; return MP_OK; }
-    if (key == MP_TUNE_GROUPS && value >= 2 && value <= MAX_GROUPS) { overlap_groups = (int)value; return MP_OK; }
+    if (key == MP_TUNE_TAU && value >= 0.0) { tau_override.store((float)value); return MP_OK; }  // 0: back to the model
+    if (key == MP_TUNE_SCREEN_PPS) { screen_pps_override.store((int)value); return MP_OK; }
+    if (key == MP_TUNE_GROUPS && value >= 2 && value <= MAX_GROUPS) { overlap_groups.store((int)value); return MP_OK; }
+    if (key == MP_TUNE_AUDIT) { audit_on.store(value != 0.0); return MP_OK; }
     return fail(MP_ERR_ARG, "mp_tune: unknown key or bad value%s");
 }
 
 int mp_profile_enable(int on) {
-    std::lock_guard<std::mutex> lk(g_prof_mu);
-    g_prof.every = on < 0 ? 0 : on;
-    g_prof.on = false;
+    g_prof.every.store(on < 0 ? 0 : on);
     return MP_OK;
 }
 
@@ -1716,14 +1767,16 @@ static int encode_impl(const float *signal, int64_t B, int64_t N, const float *d
     int n_groups = 1;
     if (K > 0 && !(flags & MP_FLAG_NO_OVERLAP) &&
         (((flags & MP_FLAG_OVERLAP) && B >= 8) ||
-         (path == MP_PATH_FFT && B >= 48 && (int64_t)g.NBLK * g.NAT < 65536)))  // big screens fill the GPU alone
-        n_groups = overlap_groups >= 2 && overlap_groups <= MAX_GROUPS ? overlap_groups : 4;
+         (path == MP_PATH_FFT && B >= 48 && (int64_t)g.NBLK * g.NAT < 65536))) {  // big screens fill the GPU alone
+        const int per_call = (flags >> MP_FLAG_GROUPS_SHIFT) & 7;                  // MP_FLAG_GROUPS(n): this call only
+        const int dflt = overlap_groups.load(std::memory_order_relaxed);
+        n_groups = per_call >= 2 && per_call <= MAX_GROUPS ? per_call : (dflt >= 2 && dflt <= MAX_GROUPS ? dflt : 4);
+    }
     StreamPool *pool = nullptr;
     if (n_groups > 1) {
-        pool = stream_pool(st);
-        if (!pool) return fail(MP_ERR_HIP, "could not create internal streams%s");
-        if (n_groups > pool->n_concurrent) n_groups = pool->n_concurrent;  // never sub-batches on one hardware queue
-        if (n_groups < 2) { n_groups = 1; pool = nullptr; }
+        pool = stream_pool(st);  // nullptr under a capture without a pool: one stream, nothing untested assumed
+        if (pool && n_groups > pool->n_concurrent) n_groups = pool->n_concurrent;  // never sub-batches on one hardware queue
+        if (!pool || n_groups < 2) { n_groups = 1; pool = nullptr; }
     }
     if (pool) {
         HIP_TRY(hipEventRecord(pool->fork, st));
@@ -1732,46 +1785,54 @@ static int encode_impl(const float *signal, int64_t B, int64_t N, const float *d
     const bool naive = path == MP_PATH_NAIVE;
     const bool incremental = path == MP_PATH_INCREMENTAL;
     const int64_t cells = (int64_t)g.NBLK * (naive ? g.A : g.NAT);
-    for (int k = 0; k < K; ++k) {
-        g_prof.arm(k);
-        for (int q = 0; q < n_groups; ++q) {
-            const int64_t b0 = B * q / n_groups, b1 = B * (q + 1) / n_groups;
-            Geom gq = g;
-            gq.B = b1 - b0;
-            Workspace wq = sub_batch(w, g, path, b0, cells);
-            hipStream_t sq = n_groups > 1 ? pool->streams[q] : st;
-            int64_t *oa = out_atom + b0 * K, *ol = out_lag + b0 * K;
-            float *og = out_gain + b0 * K;
-            if (path == MP_PATH_FFT) {
-                if ((rc = fft_iteration(gq, wq, dict_unit, K, k, flags | (n_groups == 1 ? MP_FLAG_INTERNAL_ONE_STREAM : 0),
-                                        oa, ol, og, rule, sq)))
-                    return rc;
-                continue;
+    // the K steps; whatever it returns, the forked streams are joined back into the caller's below
+    auto run_steps = [&]() -> int {
+        for (int k = 0; k < K; ++k) {
+            g_prof.arm(k);
+            for (int q = 0; q < n_groups; ++q) {
+                const int64_t b0 = B * q / n_groups, b1 = B * (q + 1) / n_groups;
+                Geom gq = g;
+                gq.B = b1 - b0;
+                Workspace wq = sub_batch(w, g, path, b0, cells);
+                hipStream_t sq = n_groups > 1 ? pool->streams[q] : st;
+                int64_t *oa = out_atom + b0 * K, *ol = out_lag + b0 * K;
+                float *og = out_gain + b0 * K;
+                int rcq;
+                if (path == MP_PATH_FFT) {
+                    if ((rcq = fft_iteration(gq, wq, dict_unit, K, k,
+                                             flags | (n_groups == 1 ? MP_FLAG_INTERNAL_ONE_STREAM : 0), oa, ol, og, rule, sq)))
+                        return rcq;
+                    continue;
+                }
+                const bool full = (k == 0) || !incremental;
+                const int *dirty = full ? nullptr : wq.dirty;
+                g_prof.begin(full ? PROF_CORR_FULL : PROF_CORR_INC, sq);
+                if (naive)
+                    rcq = launch_naive(gq, wq, dict_unit, dirty, gq.NBLK, nullptr, sq);
+                else
+                    rcq = launch_correlate<false>(gq, wq, dirty, nullptr, flags, sq);
+                g_prof.end(sq);
+                if (rcq) return rcq;
+                g_prof.begin(PROF_SELECT, sq);
+                hipLaunchKernelGGL(select_subtract_kernel, dim3((unsigned)gq.B), dim3(256), 0, sq, wq.keys, cells, wq.res,
+                                   rule.du_sub, incremental ? wq.dirty : nullptr, oa, ol, og, N, L, g.Ns, g.NBLK, K, k,
+                                   (const int *)nullptr, (const int *)nullptr, (u64 *)nullptr, (float *)nullptr,
+                                   (int64_t)0, rule.shift, rule.square);
+                g_prof.end(sq);
+                HIP_TRY(hipGetLastError());
             }
-            const bool full = (k == 0) || !incremental;
-            const int *dirty = full ? nullptr : wq.dirty;
-            g_prof.begin(full ? PROF_CORR_FULL : PROF_CORR_INC, sq);
-            if (naive)
-                rc = launch_naive(gq, wq, dict_unit, dirty, gq.NBLK, nullptr, sq);
-            else
-                rc = launch_correlate<false>(gq, wq, dirty, nullptr, flags, sq);
-            g_prof.end(sq);
-            if (rc) return rc;
-            g_prof.begin(PROF_SELECT, sq);
-            hipLaunchKernelGGL(select_subtract_kernel, dim3((unsigned)gq.B), dim3(256), 0, sq, wq.keys, cells, wq.res,
-                               rule.du_sub, incremental ? wq.dirty : nullptr, oa, ol, og, N, L, g.Ns, g.NBLK, K, k,
-                               (const int *)nullptr, (const int *)nullptr, (u64 *)nullptr, (float *)nullptr,
-                               (int64_t)0, rule.shift, rule.square);
-            g_prof.end(sq);
-            HIP_TRY(hipGetLastError());
         }
-    }
-    if (n_groups > 1) {
+        return MP_OK;
+    };
+    rc = run_steps();
+    if (n_groups > 1) {  // also after an error: a forked stream left unjoined would break the caller's capture / ordering
         for (int q = 0; q < n_groups; ++q) {
-            HIP_TRY(hipEventRecord(pool->join[q], pool->streams[q]));
-            HIP_TRY(hipStreamWaitEvent(st, pool->join[q], 0));
+            const hipError_t e1 = hipEventRecord(pool->join[q], pool->streams[q]);
+            const hipError_t e2 = e1 == hipSuccess ? hipStreamWaitEvent(st, pool->join[q], 0) : e1;
+            if (e2 != hipSuccess && rc == MP_OK) rc = fail(MP_ERR_HIP, "joining the internal streams: %s", hipGetErrorString(e2));
         }
     }
+    if (rc) return rc;
     if (path == MP_PATH_FFT && K > 0) {
         hipLaunchKernelGGL(fft_mark_overflow_kernel, dim3((unsigned)B), dim3(64), 0, st, w.overflow, out_gain, K);
         HIP_TRY(hipGetLastError());
@@ -1985,6 +2046,28 @@ int mp_conv_model_backward_f32(const float *atoms, int64_t A, int64_t L, const i
 }
 
 /* test / diagnosis hook: concurrency ratio of the internal streams q0 and q1 (see stream_pair_ratio) */
+int mp_audit_read(float *max_ratio, int64_t *cells, float *max_quarter_ratio, int64_t *over_bound) {
+    unsigned h[4] = {0, 0, 0, 0};
+    const unsigned zero[4] = {0, 0, 0, 0};
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpyFromSymbol(h, HIP_SYMBOL(g_audit), sizeof(h)));
+    HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(g_audit), zero, sizeof(zero)));
+    float r0, r2;
+    memcpy(&r0, &h[0], 4);
+    memcpy(&r2, &h[2], 4);
+    if (max_ratio) *max_ratio = r0;
+    if (cells) *cells = (int64_t)h[1];
+    if (max_quarter_ratio) *max_quarter_ratio = r2;
+    if (over_bound) *over_bound = (int64_t)h[3];
+    return MP_OK;
+}
+
+int mp_init_streams(void *stream) {
+    StreamPool *p = stream_pool(static_cast<hipStream_t>(stream));
+    if (!p) return fail(MP_ERR_HIP, "mp_init_streams: could not build the internal stream pool (called under a capture?)%s");
+    return p->n_concurrent;
+}
+
 float mp_stream_pair_ratio(int q0, int q1) {
     StreamPool *p = stream_pool(nullptr);
     if (!p || q0 < 0 || q1 < 0 || q0 >= MAX_GROUPS || q1 >= MAX_GROUPS) return -1.f;

@@ -26,6 +26,8 @@ MP_FLAG_FFT_SIMPLE = 64
 MP_TUNE_TAU = 1
 MP_TUNE_SCREEN_PPS = 2
 MP_TUNE_GROUPS = 3
+MP_TUNE_AUDIT = 4
+MP_FLAG_GROUPS_SHIFT = 20
 MP_FLAG_NO_OVERLAP = 4096
 MP_FLAG_FFT_NO_QUARTER = 8192
 MP_FLAG_FFT_QUARTER = 16384
@@ -38,8 +40,13 @@ EXPORTS = (
     "mp_feature_map_f32", "mp_scatter_f32", "mp_scatter_rows_f32", "mp_gather_sum_f32",
     "mp_profile_enable", "mp_profile_read", "mp_fft_c2c_f32", "mp_encode_conv_f32", "mp_tune",
     "mp_dictionary_update_f32", "mp_lcn_workspace_bytes", "mp_encode_lcn_f32", "mp_conv_model_backward_f32",
-    "mp_stream_pair_ratio",
+    "mp_stream_pair_ratio", "mp_init_streams", "mp_audit_read",
 )
+
+
+def flag_groups(n):
+    """MP_FLAG_GROUPS(n): this call splits its batch into n (2..4) sub-batches where it splits at all."""
+    return (int(n) & 7) << MP_FLAG_GROUPS_SHIFT
 
 _lib = None
 
@@ -79,6 +86,12 @@ def lib():
         L.mp_dictionary_update_f32.argtypes = [vp, vp, i64, i64, vp, i64, i64, vp, vp, i64, vp, vp, vp, vp,
                                                ctypes.c_float, vp, vp]
         L.mp_fft_c2c_f32.argtypes = [vp, vp, ctypes.c_int, i64, ctypes.c_int, vp, vp]
+        L.mp_init_streams.argtypes = [vp]
+        L.mp_audit_read.argtypes = [ctypes.POINTER(ctypes.c_float), ctypes.POINTER(i64),
+                                    ctypes.POINTER(ctypes.c_float), ctypes.POINTER(i64)]
+        L.mp_tune.argtypes = [ctypes.c_int, ctypes.c_double]
+        L.mp_stream_pair_ratio.restype = ctypes.c_float
+        L.mp_stream_pair_ratio.argtypes = [ctypes.c_int, ctypes.c_int]
         for name in EXPORTS:
             getattr(L, name)
         _lib = L
@@ -109,9 +122,27 @@ def _ptr(t):
 
 
 def tune(key, value):
-    """mp_tune: 1 = FFT screen tau, 2 = screen pairs-per-slot override."""
-    lib().mp_tune.argtypes = [ctypes.c_int, ctypes.c_double]
+    """mp_tune(MP_TUNE_*, value): process-wide tuning / debug knobs (include/mpcore.h)."""
     _check(lib().mp_tune(int(key), float(value)), "mp_tune")
+
+
+def init_streams(device=None):
+    """mp_init_streams: build and test this thread's internal stream pool now (host-synchronising, once) rather
+    than inside the first sub-batched encode; -> number of streams seen to run side by side."""
+    dev = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+    with torch.cuda.device(dev):
+        n = lib().mp_init_streams(ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream))
+    if n < 0:
+        raise NativeError(f"mp_init_streams failed (rc={n}): {lib().mp_last_error().decode()}")
+    return int(n)
+
+
+def audit_read():
+    """mp_audit_read (after tune(MP_TUNE_AUDIT, 1)): dict(max_ratio, cells, max_quarter_ratio, over_bound); resets."""
+    r, q = ctypes.c_float(0), ctypes.c_float(0)
+    n, o = ctypes.c_int64(0), ctypes.c_int64(0)
+    _check(lib().mp_audit_read(ctypes.byref(r), ctypes.byref(n), ctypes.byref(q), ctypes.byref(o)), "mp_audit_read")
+    return dict(max_ratio=float(r.value), cells=int(n.value), max_quarter_ratio=float(q.value), over_bound=int(o.value))
 
 
 def profile_enable(every=1):
@@ -262,12 +293,12 @@ class EncodePlan:
         self.dict_unit = dict_unit
         dev = dict_unit.device
         self.signal = torch.zeros((int(batch), int(n_samples)), dtype=torch.float32, device=dev)
-        args = dict(path=self.path, flags=flags, want_residual=want_residual)
-        tune(MP_TUNE_GROUPS, max(2, min(4, int(sub_batches))))  # (process-wide knob, restored below: see the docstring)
-        try:
-            self._capture(dev, n_steps, args)
-        finally:
-            tune(MP_TUNE_GROUPS, 4)
+        # the sub-batch count is a per-call flag: nothing process-wide is touched while other threads encode
+        args = dict(path=self.path, flags=int(flags) | flag_groups(max(2, min(4, int(sub_batches)))),
+                    want_residual=want_residual)
+        with torch.cuda.device(dev):
+            init_streams(dev)  # the pool's self-test synchronises with the host: before the capture, not inside it
+        self._capture(dev, n_steps, args)
 
     def _capture(self, dev, n_steps, args):
         side = torch.cuda.Stream(dev)

@@ -25,7 +25,9 @@ def _free_port():
 def _worker(rank, world, port, x_full, d, n_steps, ret):
     sys.path.insert(0, os.path.join(REPO, "matching-pursuit_amd"))
     import torch.distributed as dist
+    import mpcore
     from mpcore import dist as mpdist
+    mpcore.install()   # (a spawned process has no conftest: the stand-alone `modules` package, as there)
     import modules.matchingpursuit as mpm
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
                       LOCAL_RANK="0")   # both ranks on cuda:0
