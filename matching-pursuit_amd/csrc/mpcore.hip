@@ -1310,22 +1310,29 @@ std::atomic<int> overlap_groups{4};   // sub-batches when the batch is split ove
 std::atomic<float> tau_override{0.f}; // > 0: replaces the model below
 std::atomic<int> audit_on{0};         // debug: after every screen recompute the screened cells exactly (mp_audit_read)
 
-// The screen's error bound per unit of window norm.  eps = tau * ||window||_2 * max_a ||d_a||
-// must cover |screen value - fp32 fma chain| at every (atom, lag) of the window:
+// The screen's error bound.  eps(window) must cover |screen value - fp32 fma chain| at every
+// (atom, lag) of the window:
 //   * the chain's own rounding, RIGOROUSLY: acc_k = (acc_{k-1} + r_k d_k)(1 + delta_k), |delta_k| <= u = 2^-24, so
-//     |chain - exact| <= u sum_k |partial_k| (1 + O(L u)) and |partial_k| <= ||r[t .. t+k]|| ||d[0 .. k]|| <= ||window|| ||d||
-//     (Cauchy-Schwarz): <= L u ||window|| ||d||.  Same-sign atoms on a DC offset get within a small factor of it
-//     (partial sums grow linearly and the roundings share a sign inside a binade); random data stay near sqrt(L) u.
-//   * the three fp32 transforms and the spectrum product, MODELLED: c log2(M) u ||window|| ||d|| -- rounding errors of
-//     a Stockham FFT grow with the number of butterfly levels and are relative to the RMS of the result, itself
-//     <= ||window|| ||d||.  c = 4 puts the largest |screen - exact| ever seen by the audit mode (MP_TUNE_AUDIT;
-//     random, planted, DC-offset / same-sign, transient and 1e-30 / 1e18-amplitude inputs, L = 1 .. 8192) below a
-//     quarter of the bound (tests/test_gpu_parity.py::test_screen_error_bound_audit).
+//     |chain - exact| <= u (1 + u)^L sum_k |partial_k|, and sum_k |partial_k| <= sum_j (L - j) |r_j| |d_j|
+//     <= ||r[t .. t+L)|| W_a <= ||window|| W_a (Cauchy-Schwarz), W_a = sqrt(sum_j (L - j)^2 d_a[j]^2): 0.58 L for
+//     an atom of even energy, L at worst.  Same-sign atoms on a DC offset are the inputs that come within a small
+//     factor of it (partial sums grow linearly; with constant increments the roundings share a sign inside a
+//     binade); random data stay near sqrt(L) u.
+//   * the three fp32 transforms and the spectrum product, MODELLED: c log2(M) u ||window|| ||d_a|| -- the rounding
+//     error of a Stockham FFT grows with the number of butterfly levels and is relative to the RMS of the result,
+//     itself <= ||window|| ||d_a||.  With c = 4 this term ALONE exceeds the largest |screen - chain| the audit mode
+//     (MP_TUNE_AUDIT) has seen on random, planted, DC-offset / same-sign, transient and 1e-30 / 1e18-amplitude
+//     inputs for L = 16 .. 8192 (scripts/screen_audit.py: at most 41 u ||window|| at L = 8192, 24 u at L = 512), and
+//     the whole bound was used to at most 0.09 (tests/test_gpu_parity.py::test_screen_error_bound_audit).
+//   eps = u ||window|| max_a (1.001 W_a + 4 log2(M) ||d_a||):  the kernels multiply `tau` (= u here) with
+//   wnorm = ||window|| * dscale, dscale = the dictionary factor (max_row_norm_kernel).
+// mp_tune(MP_TUNE_TAU, x > 0) replaces it by the constant form eps = x ||window|| max_a ||d_a|| (round 1 used 2e-5).
 constexpr float FFT_TAU_C = 4.0f;
-float fft_tau(int64_t L, int logM) {
+struct TauModel { float tau, chain_w, fft_w; };
+TauModel fft_tau(int logM) {
     const float o = tau_override.load(std::memory_order_relaxed);
-    if (o > 0.f) return o;
-    return (1.01f * (float)L + FFT_TAU_C * (float)logM) * 5.9604645e-8f;
+    if (o > 0.f) return TauModel{o, 0.f, 1.f};
+    return TauModel{5.9604645e-8f, 1.001f, FFT_TAU_C * (float)logM};
 }
 
 // once per encode, whole batch, on the caller's stream: twiddles, pair spectra, cleared keys / flags
@@ -1379,7 +1386,7 @@ int fft_iteration(const Geom &g, const Workspace &w, const float *du, int K, int
                   int64_t *out_lag, float *out_gain, const Rule &rule, hipStream_t st) {
     FftGeom f;
     if (!make_fft_geom(g, &f)) return fail(MP_ERR_UNSUPPORTED, "MP_PATH_FFT: atom too long%s");
-    const float tau = fft_tau(g.L, f.logM);
+    const float tau = fft_tau(f.logM).tau;
     // split transforms: the four-kernel form between screens (the window kernel makes the next spectrum)
     if (f.split) flags = (flags | MP_FLAG_FFT_UNFUSED) & ~(MP_FLAG_FFT_FUSED | MP_FLAG_FFT_QUARTER);
     const size_t lds = (size_t)(f.split ? f.M / 2 : f.M) * sizeof(cpx);
@@ -1581,7 +1588,7 @@ float stream_pair_ratio(hipStream_t a, hipStream_t b) {
     ok = ok && hipEventRecord(ea, a) == hipSuccess && hipEventRecord(eb, b) == hipSuccess &&
          hipEventSynchronize(ea) == hipSuccess && hipEventSynchronize(eb) == hipSuccess &&
          hipEventElapsedTime(&ta, e0, ea) == hipSuccess && hipEventElapsedTime(&tb, e0, eb) == hipSuccess;
-    hipEventDestroy(e0); hipEventDestroy(ea); hipEventDestroy(eb);
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(ea); (void)hipEventDestroy(eb);
     if (!ok || one <= 0.f) return -1.f;
     return (ta > tb ? ta : tb) / one;
 }
@@ -1750,8 +1757,12 @@ static int encode_impl(const float *signal, int64_t B, int64_t N, const float *d
     if (path == MP_PATH_FFT) {
         // the screen's bound |fm| <= ||window|| * max_a ||d_a||: 1 for the unit-norm dictionary this entry point
         // is documented for, but measured rather than trusted (and the convolution model's atoms are raw)
+        FftGeom f;
+        if (!make_fft_geom(g, &f)) return fail(MP_ERR_UNSUPPORTED, "MP_PATH_FFT: atom too long%s");
+        const TauModel tm = fft_tau(f.logM);
         HIP_TRY(hipMemsetAsync(w.dscale, 0, sizeof(float), st));
-        hipLaunchKernelGGL(max_row_norm_kernel, dim3((unsigned)((A + 3) / 4)), dim3(256), 0, st, dict_in, A, L, w.dscale);
+        hipLaunchKernelGGL(max_row_norm_kernel, dim3((unsigned)((A + 3) / 4)), dim3(256), 0, st, dict_unit, A, L, w.dscale,
+                           tm.chain_w, tm.fft_w);
         HIP_TRY(hipGetLastError());
     }
 

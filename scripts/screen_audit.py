@@ -29,8 +29,13 @@ def log2m(L):
     return lg
 
 
-def tau_model(L):
-    return (1.01 * L + 4.0 * log2m(L)) * U
+def bound_per_unit_window(d_raw):
+    """eps / ||window|| as the library forms it (mpcore.hip::fft_tau, max_row_norm_kernel), unit-normed atoms."""
+    d = d_raw.astype(np.float64)
+    d = d / (np.linalg.norm(d, axis=-1, keepdims=True) + 1e-8)
+    L = d.shape[1]
+    W = np.sqrt(((L - np.arange(L)) ** 2 * d * d).sum(-1))
+    return float((1.0001 * (1.001 * W + 4.0 * log2m(L))).max() * U)
 
 
 def run(name, x, d_raw, K, flags=0):
@@ -41,10 +46,11 @@ def run(name, x, d_raw, K, flags=0):
     a = nat.audit_read()
     L = d_raw.shape[1]
     marked = int(torch.isnan(out[2]).any(dim=1).sum())
-    err_u = a["max_ratio"] * tau_model(L) / U
+    bound = bound_per_unit_window(d_raw)
+    err_u = a["max_ratio"] * bound / U
     print(f"{name:44s} L={L:5d} log2M={log2m(L):2d} cells={a['cells']:8d} ratio={a['max_ratio']:.4f} "
           f"quarter={a['max_quarter_ratio']:.4f} over={a['over_bound']} err={err_u:8.1f} u*||w||  "
-          f"(sqrt(L)={math.sqrt(L):.0f}, L={L}) marked={marked}", flush=True)
+          f"(bound {bound / U:7.0f} u; sqrt(L)={math.sqrt(L):.0f}) marked={marked}", flush=True)
     return a
 
 
@@ -71,8 +77,8 @@ def main():
             ("DC 0.3 + events, random atoms", adv.dc_offset_segments(B, N, du.astype(np.float32), 8, 79 + L), d),
         ]
         for name, x, dd in cases:
-            for fname, flags in (("", 0), (" [one stream]", nat.MP_FLAG_NO_OVERLAP)):
-                if fname and L > 512:
+            for fname, flags in (("", 0), (" [quarter cells]", nat.MP_FLAG_FFT_QUARTER)):
+                if fname and not 128 <= L <= 512:
                     continue
                 a = run(name + fname, x, dd, K, flags)
                 worst = max(worst, a["max_ratio"], a["max_quarter_ratio"])

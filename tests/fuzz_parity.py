@@ -2,18 +2,27 @@
 """Randomised parity sweep: the default schedule (and a few others) against the CPU oracle, bitwise, on shapes
 no fixed test uses -- odd atom counts, atoms longer than the segment's tail, batches that split unevenly
 into sub-batches, segments shorter than one transform.  Lives under tests/ because it uses the oracle (test
-infrastructure); not collected by pytest -- run it by hand:   python tests/fuzz_parity.py [n_cases] [seed]"""
+infrastructure); not collected by pytest -- run it by hand:   python tests/fuzz_parity.py [n_cases] [seed] [audit]
+With a third argument the library runs in audit mode (mp_tune(MP_TUNE_AUDIT, 1)): after every FFT screen each
+screened cell is recomputed exactly, and the sweep ends with the largest |screen - exact| / eps it saw."""
 import os, sys
 import numpy as np, torch
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(REPO, "matching-pursuit_amd"))
 sys.path.insert(0, os.path.join(REPO, "oracle"))
+sys.path.insert(0, os.path.join(REPO, "tests"))
+import adversarial as adv
 from mpcore import _native as nat
 from mpcore import synth
 import mp_oracle
 mp_oracle.build()
 n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 40
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 2024)
+AUDIT = len(sys.argv) > 3
+if AUDIT:
+    nat.tune(nat.MP_TUNE_AUDIT, 1)
+    nat.audit_read()
+audit_worst = dict(max_ratio=0.0, max_quarter_ratio=0.0, cells=0, over_bound=0)
 paths = [("fft", nat.MP_PATH_FFT, 0), ("fft_one_stream", nat.MP_PATH_FFT, nat.MP_FLAG_NO_OVERLAP),
          ("fft_scan_refine", nat.MP_PATH_FFT, nat.MP_FLAG_FFT_NO_QUARTER), ("fft_quarter", nat.MP_PATH_FFT, nat.MP_FLAG_FFT_QUARTER), ("fft_fused", nat.MP_PATH_FFT, nat.MP_FLAG_FFT_FUSED),
          ("incremental", nat.MP_PATH_INCREMENTAL, 0)]
@@ -41,6 +50,13 @@ for case in range(n_cases):
             x[:, p0:p0 + L] += d[0] / np.linalg.norm(d[0])
     if case % 10 == 8:   # tiny and huge amplitudes
         x = (x * (1e-30 if case % 20 == 8 else 1e18)).astype(np.float32)
+    if case % 10 == 5 and N > 2 * L:   # same-sign atoms on a DC offset (the chain's rounding at its most biased) / one 1e3 transient among 1e-4 samples
+        if case % 20 == 5:
+            d = adv.same_sign_dictionary(A, L, 3000 + case)
+            x = adv.dc_offset_segments(B, N, (d / np.linalg.norm(d, axis=-1, keepdims=True)).astype(np.float32), 8, 3100 + case,
+                                       dc=float(rng.choice([0.3, 30.0])))
+        else:
+            x = adv.transient_segments(B, N, (d / np.linalg.norm(d, axis=-1, keepdims=True)).astype(np.float32), 8, 3200 + case)
     du = mp_oracle.unit_norm(d)
     want = mp_oracle.encode(x, du, K)
     gap = (want["top2"][..., 0] - want["top2"][..., 1]) / np.maximum(np.abs(want["top2"][..., 0]), 1e-30)
@@ -67,8 +83,15 @@ for case in range(n_cases):
                 np.array_equal(r, wl["residual"])):
             bad += 1
             print(f"MISMATCH case {case} lcn: A{A} L{L} N{N} B{B} K{K}", flush=True)
+    if AUDIT:
+        a = nat.audit_read()
+        audit_worst = dict(max_ratio=max(audit_worst["max_ratio"], a["max_ratio"]),
+                           max_quarter_ratio=max(audit_worst["max_quarter_ratio"], a["max_quarter_ratio"]),
+                           cells=audit_worst["cells"] + a["cells"], over_bound=audit_worst["over_bound"] + a["over_bound"])
+        if a["over_bound"] or a["max_ratio"] > 0.25:
+            print(f"AUDIT case {case}: A{A} L{L} N{N} B{B} K{K} {a}", flush=True)
     if case % 10 == 9:
-        print(f"{case + 1} cases done, {bad} mismatches", flush=True)
+        print(f"{case + 1} cases done, {bad} mismatches" + (f", audit so far {audit_worst}" if AUDIT else ""), flush=True)
 # the convolution model of mp.py (raw atoms, v^2 update, no oracle): its three schedules must agree with each other
 conv_bad = 0
 for case in range(max(n_cases // 5, 4)):
@@ -87,5 +110,9 @@ for case in range(max(n_cases // 5, 4)):
             print(f"CONV MISMATCH case {case} {name}: A{A} L{L} N{N} B{B} K{K}", flush=True)
 print("convolution-model schedules agree:", "OK" if conv_bad == 0 else f"{conv_bad} MISMATCHES", flush=True)
 bad += conv_bad
+if AUDIT:
+    nat.tune(nat.MP_TUNE_AUDIT, 0)
+    print("screen audit: largest |screen - exact| / eps", audit_worst, flush=True)
+    bad += audit_worst["over_bound"]
 print("fuzz parity:", "OK" if bad == 0 else f"{bad} MISMATCHES", f"({marked} segment-runs marked as screen overflow)", flush=True)
 sys.exit(1 if bad else 0)

@@ -491,3 +491,233 @@ def test_two_host_threads_encode_concurrently(oracle):
     for i in range(2):
         assert np.array_equal(got[i][0], want[i]["atom"]) and np.array_equal(got[i][1], want[i]["lag"])
         assert np.array_equal(got[i][2], want[i]["gain"]) and np.array_equal(got[i][3], want[i]["residual"])
+
+
+# ---- the FFT screen's error bound: adversarial inputs and the audit mode ---------------------------------------
+def _adversarial(kind, A, L, N, B, seed):
+    import adversarial as adv
+    if kind == "dc_same_sign":
+        d = adv.same_sign_dictionary(A, L, seed)
+        du = (d / np.linalg.norm(d, axis=-1, keepdims=True)).astype(np.float32)
+        return d, adv.dc_offset_segments(B, N, du, 8, seed + 1)
+    if kind == "dc30_same_sign":
+        d = adv.same_sign_dictionary(A, L, seed)
+        du = (d / np.linalg.norm(d, axis=-1, keepdims=True)).astype(np.float32)
+        return d, adv.dc_offset_segments(B, N, du, 8, seed + 1, dc=30.0)
+    if kind == "transient":
+        d = synth.make_dictionary(A, L, seed=seed)
+        du = (d / np.linalg.norm(d, axis=-1, keepdims=True)).astype(np.float32)
+        return d, adv.transient_segments(B, N, du, 8, seed + 1)
+    raise ValueError(kind)
+
+
+@pytest.mark.parametrize("kind,A,L,N,K", [
+    ("dc_same_sign", 12, 2048, 12000, 5), ("dc_same_sign", 6, 8192, 20000, 4), ("dc30_same_sign", 12, 2048, 12000, 5),
+    ("dc_same_sign", 40, 512, 6000, 6), ("transient", 12, 2048, 12000, 5), ("transient", 40, 512, 6000, 6),
+    ("transient", 6, 8192, 20000, 4)])
+def test_adversarial_inputs_bitwise_vs_oracle(oracle, kind, A, L, N, K):
+    """Where the fp32 chain's own rounding is largest and most biased (same-sign atoms on a DC offset, long atoms)
+    and where a window's norm says little about its cells (one 1e3 transient among 1e-4 samples): every FFT
+    schedule returns the oracle's events bit for bit, or marks the segment -- never a silent difference."""
+    sys_path_tests()
+    d, x = _adversarial(kind, A, L, N, 2, seed=900 + L)
+    du = oracle.unit_norm(d)
+    want = oracle.encode(x, du, K)
+    unmarked = 0
+    for flags in (0, nat.MP_FLAG_FFT_FUSED, nat.MP_FLAG_FFT_UNFUSED, nat.MP_FLAG_FFT_QUARTER):
+        atom, lag, gain, res = _gpu_encode(x, du, K, nat.MP_PATH_FFT, flags)
+        keep = ~np.isnan(gain).any(axis=1)
+        unmarked += int(keep.sum())
+        for name, got in (("atom", atom), ("lag", lag), ("gain", gain), ("residual", res)):
+            assert np.array_equal(got[keep], want[name][keep]), (name, kind, L, flags)
+    assert unmarked > 0   # the test must not pass by marking everything
+    # ... and through the checked default (marked segments re-encoded on the incremental schedule): always exact
+    a, l, g, r = nat.encode_checked(torch.from_numpy(x).to(DEV), torch.from_numpy(du).to(DEV), K)
+    assert np.array_equal(a.cpu().numpy(), want["atom"]) and np.array_equal(l.cpu().numpy(), want["lag"])
+    assert np.array_equal(g.cpu().numpy(), want["gain"]) and np.array_equal(r.cpu().numpy(), want["residual"])
+
+
+def sys_path_tests():
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    if here not in sys.path:
+        sys.path.insert(0, here)
+
+
+def test_screen_error_bound_audit():
+    """mp_tune(MP_TUNE_AUDIT): after every screen each screened cell is recomputed exactly and
+    |screen - exact| / eps recorded.  The selection is exact while that stays <= 1; the bound's transform term was
+    sized so that it stays <= 0.25 (measured worst over scripts/screen_audit.py's sweep: 0.10)."""
+    sys_path_tests()
+    nat.tune(nat.MP_TUNE_AUDIT, 1)
+    try:
+        worst, cells = 0.0, 0
+        for kind, A, L, N in (("planted", 40, 16, 2000), ("planted", 64, 128, 4096), ("planted", 96, 512, 12000),
+                              ("dc_same_sign", 40, 512, 6000), ("transient", 40, 512, 6000),
+                              ("planted", 32, 2048, 30000), ("dc_same_sign", 12, 2048, 12000),
+                              ("dc_same_sign", 6, 8192, 20000), ("planted_tiny", 64, 128, 4096)):
+            if kind.startswith("planted"):
+                d = synth.make_dictionary(A, L, seed=70 + L)
+                x = synth.make_segments(3, N, d, n_events=12, seed=71 + L)
+                if kind == "planted_tiny":
+                    x = (x * 1e-30).astype(np.float32)
+            else:
+                d, x = _adversarial(kind, A, L, N, 3, seed=900 + L)
+            du = nat.unit_norm(torch.from_numpy(d).to(DEV))
+            for flags in ((0, nat.MP_FLAG_FFT_QUARTER) if 128 <= L <= 512 else (0,)):
+                nat.audit_read()
+                nat.encode(torch.from_numpy(x).to(DEV), du, 5, path=nat.MP_PATH_FFT, flags=flags)
+                a = nat.audit_read()
+                assert a["cells"] > 0 and a["over_bound"] == 0, (kind, L, a)
+                assert a["max_ratio"] <= 0.25 and a["max_quarter_ratio"] <= 0.25, (kind, L, a)
+                worst = max(worst, a["max_ratio"], a["max_quarter_ratio"])
+                cells += a["cells"]
+        assert cells > 10000 and worst > 0.0   # the audit really looked at cells and saw nonzero errors
+        # a bound that is too small IS reported: 1e-9 ||window|| is below the screen's rounding error
+        nat.tune(nat.MP_TUNE_TAU, 1e-9)
+        d = synth.make_dictionary(96, 512, seed=70)
+        x = synth.make_segments(2, 12000, d, n_events=12, seed=71)
+        nat.encode(torch.from_numpy(x).to(DEV), nat.unit_norm(torch.from_numpy(d).to(DEV)), 3, path=nat.MP_PATH_FFT)
+        assert nat.audit_read()["over_bound"] > 0
+    finally:
+        nat.tune(nat.MP_TUNE_TAU, 0)
+        nat.tune(nat.MP_TUNE_AUDIT, 0)
+
+
+def test_encode_plan_built_while_another_thread_encodes(oracle):
+    """EncodePlan passes its sub-batch count as a per-call flag (MP_FLAG_GROUPS) and builds its stream pool with
+    mp_init_streams before capturing: constructing and replaying plans must not disturb an encode running in
+    another host thread (round 1 toggled a process-wide knob here)."""
+    import threading
+    d = synth.make_dictionary(40, 96, seed=51)
+    du_np = oracle.unit_norm(d)
+    du = torch.from_numpy(du_np).to(DEV)
+    x = synth.make_segments(50, 3000, d, n_events=10, seed=52)
+    want = oracle.encode(x, du_np, 6)
+    stop = threading.Event()
+    errors, rounds = [], [0]
+
+    def encoder():
+        try:
+            stream = torch.cuda.Stream(DEV)
+            xd = torch.from_numpy(x).to(DEV)
+            stream.wait_stream(torch.cuda.current_stream(DEV))
+            with torch.cuda.stream(stream):
+                while not stop.is_set():
+                    out = nat.encode(xd, du, 6, path=nat.MP_PATH_FFT)   # 50 segments: the default four sub-batches
+                    stream.synchronize()
+                    got = [t.cpu().numpy() for t in out]
+                    assert np.array_equal(got[0], want["atom"]) and np.array_equal(got[2], want["gain"])
+                    rounds[0] += 1
+        except Exception as e:  # noqa: BLE001
+            errors.append(repr(e))
+
+    t = threading.Thread(target=encoder)
+    t.start()
+    try:
+        xd = torch.from_numpy(x).to(DEV)
+        for sub in (2, 3, 4, 2):
+            plan = nat.EncodePlan(50, 3000, du, 6, sub_batches=sub)
+            a, l, g, r = plan(xd)
+            torch.cuda.synchronize()
+            assert np.array_equal(a.cpu().numpy(), want["atom"]) and np.array_equal(l.cpu().numpy(), want["lag"])
+            assert np.array_equal(g.cpu().numpy(), want["gain"]) and np.array_equal(r.cpu().numpy(), want["residual"])
+    finally:
+        stop.set()
+        t.join()
+    assert not errors, errors
+    assert rounds[0] >= 1
+
+
+def test_init_streams_and_capture_in_a_thread_without_a_pool(oracle):
+    """mp_init_streams reports how many internal streams run side by side (idempotent); a thread that captures an
+    encode WITHOUT having built its pool gets a one-stream graph (nothing untested is assumed under capture) with
+    the same results."""
+    import threading
+    n = nat.init_streams()
+    assert 1 <= n <= 4 and nat.init_streams() == n
+    d = synth.make_dictionary(40, 96, seed=51)
+    du_np = oracle.unit_norm(d)
+    x = synth.make_segments(50, 3000, d, n_events=10, seed=52)
+    want = oracle.encode(x, du_np, 4)
+    out, errors = [None], []
+
+    def fresh_thread():
+        try:
+            du = torch.from_numpy(du_np).to(DEV)
+            xs = torch.from_numpy(x).to(DEV)
+            torch.cuda.synchronize()
+            side = torch.cuda.Stream(DEV)
+            with torch.cuda.stream(side):
+                graph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(graph, stream=side):
+                    res = nat.encode(xs, du, 4, path=nat.MP_PATH_FFT)   # this thread has no stream pool yet
+                graph.replay()
+            torch.cuda.synchronize()
+            out[0] = [t.cpu().numpy() for t in res]
+        except Exception as e:  # noqa: BLE001
+            errors.append(repr(e))
+
+    t = threading.Thread(target=fresh_thread)
+    t.start()
+    t.join()
+    assert not errors, errors
+    assert np.array_equal(out[0][0], want["atom"]) and np.array_equal(out[0][1], want["lag"])
+    assert np.array_equal(out[0][2], want["gain"]) and np.array_equal(out[0][3], want["residual"])
+
+
+# ---- BASELINE.json configs at FULL size --------------------------------------------------------------------------
+def test_config1_full_size_default_schedule(oracle):
+    """configs[1]: 512 x 512 dictionary, B = 64 segments of 32768 samples, K = 64 on the library default (four
+    sub-batches on forked streams).  Size-independent properties over the whole job, the oracle on a 4-segment x
+    16-step sample, and the one-stream and incremental schedules bit for bit."""
+    A, L, N, B, K = 512, 512, 32768, 64, 64
+    d = synth.make_dictionary(A, L, seed=1000)
+    x_host = synth.make_segments(B, N, d, n_events=3 * K, seed=1002)
+    x = torch.from_numpy(x_host).to(DEV)
+    du = nat.unit_norm(torch.from_numpy(d).to(DEV))
+    atom, lag, gain, residual = nat.encode(x, du, K, path=nat.MP_PATH_FFT)
+    torch.cuda.synchronize()
+    assert not torch.isnan(gain).any()                       # no screen overflow anywhere in the job
+    assert (atom >= 0).all() and (atom < A).all() and (lag >= 0).all() and (lag < N).all()
+    recon = torch.zeros_like(x)
+    nat.scatter(atom, torch.arange(B, device=DEV)[:, None].expand(B, K), lag, gain, du, recon)
+    assert (recon + residual - x).abs().max().item() <= 4 * REL * x.abs().max().item()
+    e0, e1 = (x.double() ** 2).sum(-1), (residual.double() ** 2).sum(-1)
+    interior = lag + L <= N
+    assert (e1 < e0).all() and ((e0 - e1) >= 0.99 * ((gain.double() ** 2) * interior).sum(-1)).all()
+    # per-step energy is non-increasing along every segment: replay the events step by step on a sample
+    one = nat.encode(x, du, K, path=nat.MP_PATH_FFT, flags=nat.MP_FLAG_NO_OVERLAP)
+    assert all(torch.equal(p, q) for p, q in zip(one, (atom, lag, gain, residual)))
+    inc = nat.encode(x[:8], du, K, path=nat.MP_PATH_INCREMENTAL)
+    assert torch.equal(inc[0], atom[:8]) and torch.equal(inc[1], lag[:8]) and torch.equal(inc[2], gain[:8])
+    assert torch.equal(inc[3], residual[:8])
+    want = oracle.encode(x_host[:4], du.cpu().numpy(), 16)
+    assert np.array_equal(atom[:4, :16].cpu().numpy(), want["atom"]) and np.array_equal(lag[:4, :16].cpu().numpy(), want["lag"])
+    assert np.array_equal(gain[:4, :16].cpu().numpy(), want["gain"])
+
+
+def test_config3_full_size_default_schedule():
+    """configs[3]: 4096 x 2048 dictionary, B = 128 segments of 131072 samples, K = 256 on the default schedule
+    (FFT screen, whole-cell select with block summaries): no overflow marks, decode(events) + residual = signal,
+    energy accounting, and events equal to MP_PATH_INCREMENTAL on a 4-segment x 16-step prefix."""
+    A, L, N, B, K = 4096, 2048, 131072, 128, 256
+    d = synth.make_dictionary(A, L, seed=4000)
+    du = nat.unit_norm(torch.from_numpy(d).to(DEV))
+    x = torch.empty(B, N, device=DEV)
+    for b0 in range(0, B, 16):  # (synthesis on the host, 16 segments at a time)
+        x[b0:b0 + 16] = torch.from_numpy(synth.make_segments(16, N, d, n_events=192, seed=4001, first_index=b0)).to(DEV)
+    atom, lag, gain, residual = nat.encode(x, du, K, path=nat.MP_PATH_FFT)
+    torch.cuda.synchronize()
+    assert not torch.isnan(gain).any()
+    assert (atom >= 0).all() and (atom < A).all() and (lag >= 0).all() and (lag < N).all()
+    recon = torch.zeros_like(x)
+    nat.scatter(atom, torch.arange(B, device=DEV)[:, None].expand(B, K), lag, gain, du, recon)
+    assert (recon + residual - x).abs().max().item() <= 8 * REL * x.abs().max().item()
+    e0, e1 = (x.double() ** 2).sum(-1), (residual.double() ** 2).sum(-1)
+    interior = lag + L <= N
+    assert (e1 < e0).all() and ((e0 - e1) >= 0.99 * ((gain.double() ** 2) * interior).sum(-1)).all()
+    assert (gain[:, 0:1] >= gain - 1e-6).all()              # the first event of a segment is its largest
+    inc = nat.encode(x[:4], du, 16, path=nat.MP_PATH_INCREMENTAL)
+    torch.cuda.synchronize()
+    assert torch.equal(inc[0], atom[:4, :16]) and torch.equal(inc[1], lag[:4, :16]) and torch.equal(inc[2], gain[:4, :16])
