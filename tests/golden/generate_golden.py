@@ -449,6 +449,27 @@ def loss_and_approx_fixtures(mp, conv, norm):
         print(f"  approx={tag}: min relative top-2 gap {float(gap.min()):.3e}; atoms used {sorted(set(enc['atom'].reshape(-1).tolist()))}")
     np.savez_compressed(os.path.join(HERE, "approx_correlation.npz"), **out)
 
+    # --- more than one channel.  sparse_code on a [B, C, N] signal with a [A, C, L] dictionary does not run in the
+    # reference: the first scatter assigns a [C, L] block to one channel row (:49-52) and raises.  What does work is
+    # the DECODER's multi-channel branch: scatter((B, C, N), events) puts the i-th event of a segment on channel i.
+    rng = np.random.Generator(np.random.PCG64(1717))
+    raised = ""
+    try:
+        mp.sparse_code(torch.from_numpy(rng.standard_normal((2, 2, 256)).astype(np.float32)),
+                       torch.from_numpy(rng.standard_normal((5, 2, 16)).astype(np.float32)), n_steps=3, flatten=True)
+    except Exception as e:  # noqa: BLE001
+        raised = type(e).__name__
+    Bm, Cm, Nm, Lm = 2, 3, 64, 8
+    rows = rng.standard_normal((5, Lm)).astype(np.float32)
+    ev_batch = np.array([0, 1, 0, 0, 1], dtype=np.int64)
+    ev_lag = np.array([3, 60, 10, 3, 0], dtype=np.int64)          # one cropped at N, two of segment 0 at the same lag
+    ev = [(int(i), int(b), torch.tensor([[int(p)]]), torch.from_numpy(rows[i]).view(1, 1, Lm))
+          for i, (b, p) in enumerate(zip(ev_batch, ev_lag))]
+    dec = mp.build_scatter_segments(Nm, Lm)((Bm, Cm, Nm), ev).detach().numpy()
+    np.savez_compressed(os.path.join(HERE, "multichannel.npz"), sparse_code_raises=np.array(raised), rows=rows,
+                        ev_batch=ev_batch, ev_lag=ev_lag, decoded=dec)
+    print("  multi-channel: sparse_code raises", raised, "| decoder channels", dec.shape)
+
 
 if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "loss":  # only the loss / approximate-correlation fixtures

@@ -282,6 +282,25 @@ def test_approximate_correlation_matches_reference(golden_dir):
         assert sorted((e[0], e[1], int(e[2])) for e in ev2) == sorted((e[0], e[1], int(e[2])) for e in events)
 
 
+def test_multichannel_behaviour_matches_reference(golden_dir):
+    """More than one channel: the reference's sparse_code raises a RuntimeError at its first scatter (:49-52) -- so
+    does this one, up front; the decoder's multi-channel branch (the i-th event of a segment goes to channel i,
+    assigned, cropped at N) is the reference's."""
+    z = np.load(os.path.join(golden_dir, "multichannel.npz"))
+    assert str(z["sparse_code_raises"]) == "RuntimeError"
+    with pytest.raises(RuntimeError):
+        mp.sparse_code(torch.zeros(2, 2, 256, device=DEV), torch.rand(5, 2, 16, device=DEV), n_steps=3, flatten=True)
+    with pytest.raises(RuntimeError):
+        mp.dictionary_learning_step(torch.zeros(2, 2, 256, device=DEV), torch.rand(5, 2, 16, device=DEV), n_steps=3)
+    L = z["rows"].shape[1]
+    B, C, N = z["decoded"].shape
+    for dev in (DEV, "cpu"):
+        ev = [(i, int(b), torch.tensor([[int(p)]], device=dev), torch.from_numpy(z["rows"][i]).to(dev).view(1, 1, L))
+              for i, (b, p) in enumerate(zip(z["ev_batch"], z["ev_lag"]))]
+        got = mp.build_scatter_segments(N, L)((B, C, N), ev)
+        assert got.shape == (B, C, N) and np.array_equal(got.cpu().numpy(), z["decoded"])
+
+
 def test_unit_norm_and_conv_wrappers(golden_dir):
     import modules
     import modules.conv as conv
