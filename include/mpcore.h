@@ -261,6 +261,28 @@ int mp_dictionary_update_f32(float *residual, float *sparse_zeroed, int64_t B, i
                              const int64_t *ev_batch, const int64_t *ev_lag, const float *ev_rows,
                              const float *ev_norm, float eps, const int *overlap, void *stream);
 
+/*
+ * The same loop spread over the chip (single device).  An atom's update touches only the samples under its own
+ * events, so it depends on an earlier atom only where their events share a sample.
+ *
+ * mp_dictionary_levels_host -- HOST pointers, no device work: from the grouped events (offsets [n_groups + 1],
+ * ev_batch / ev_lag [n_events], as above but in host memory) computes level[g] = 0 for a group that overlaps no
+ * earlier group, else 1 + the highest level among the earlier groups it overlaps; overlap[g] = 1 if two events of
+ * group g itself share a sample; *n_levels = highest level + 1.  O(E log E + overlapping pairs).
+ *
+ * mp_dictionary_update_levels_f32 -- as mp_dictionary_update_f32, one launch per level and one workgroup per
+ * atom: group_list (DEVICE, [n_groups]) lists the groups sorted by level (ascending group index inside a level),
+ * level_offsets_host (HOST, [n_levels + 1]) delimits the levels in it; overlap is the device copy of the array
+ * above.  Every sample sees the same operations in the same order as in the one-launch form: bit-identical.
+ */
+int mp_dictionary_levels_host(const int64_t *offsets, int64_t n_groups, const int64_t *ev_batch, const int64_t *ev_lag,
+                              int64_t n_events, int64_t L, int32_t *level, int32_t *overlap, int64_t *n_levels);
+int mp_dictionary_update_levels_f32(float *residual, float *sparse_zeroed, int64_t B, int64_t N, float *dict_work,
+                                    int64_t A, int64_t L, const int64_t *order, const int64_t *offsets, int64_t n_groups,
+                                    const int64_t *ev_batch, const int64_t *ev_lag, const float *ev_rows,
+                                    const float *ev_norm, float eps, const int *overlap, const int64_t *group_list,
+                                    const int64_t *level_offsets_host, int64_t n_levels, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -21,6 +21,7 @@
 #include <stdio.h>
 #include <string.h>
 
+#include <algorithm>
 #include <atomic>
 #include <mutex>
 #include <vector>
@@ -906,17 +907,15 @@ __global__ void gather_sum_kernel(const float *__restrict__ x, int64_t N, const 
 //   d[order[g]] = new;  sparse = scatter(new * ||row_e||);  residual -= sparse               (:406-415)
 // `sparse` is a zeroed [B, N] scratch; the kernel re-zeroes what it touched.
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(1024) void dictionary_update_kernel(
-    float *__restrict__ residual, float *__restrict__ sparse, int64_t N, float *__restrict__ d_work, int64_t L,
-    const int64_t *__restrict__ order, const int64_t *__restrict__ off, int64_t n_groups,
+// one group (= one used atom) of the loop, by the 1024 threads of a workgroup; ends with a barrier
+__device__ __forceinline__ void dictionary_update_group(
+    const int64_t g, float *residual, float *sparse, int64_t N, float *d_work, int64_t L,
+    const int64_t *__restrict__ order, const int64_t *__restrict__ off,
     const int64_t *__restrict__ ev_batch, const int64_t *__restrict__ ev_lag, const float *__restrict__ ev_rows,
-    const float *__restrict__ ev_norm, float eps, const int *__restrict__ overlap, int64_t win_cap) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    float *nw = reinterpret_cast<float *>(smem);  // the new atom, L floats
-    float *win = nw + L;                          // win_cap floats: an atom's residual windows (see below)
-    __shared__ float s_den;
+    const float *__restrict__ ev_norm, float eps, const int *__restrict__ overlap, int64_t win_cap, float *nw, float *win,
+    float &s_den) {
     const int tid = threadIdx.x;
-    for (int64_t g = 0; g < n_groups; ++g) {
+    {
         const int64_t e0 = off[g], e1 = off[g + 1];
         // An atom none of whose events overlap (overlap[g] == 0: the caller checked -- almost every atom) needs no
         // staging in `sparse` and no event-after-event order: 0 + row == row exactly, so adding the rows straight
@@ -963,7 +962,7 @@ __global__ __launch_bounds__(1024) void dictionary_update_kernel(
                     residual[ev_batch[e] * N + t] = __fsub_rn(win[(int64_t)el * L + sidx], __fmul_rn(nw[sidx], ev_norm[e]));
             }
             __syncthreads();  // the next atom reads what this one wrote
-            continue;
+            return;
         }
         if (apart) {
             for (int64_t idx = tid; idx < span; idx += 1024) {
@@ -1038,6 +1037,40 @@ __global__ __launch_bounds__(1024) void dictionary_update_kernel(
             __syncthreads();
         }
     }
+}
+
+__global__ __launch_bounds__(1024) void dictionary_update_kernel(
+    float *residual, float *sparse, int64_t N, float *d_work, int64_t L,
+    const int64_t *__restrict__ order, const int64_t *__restrict__ off, int64_t n_groups,
+    const int64_t *__restrict__ ev_batch, const int64_t *__restrict__ ev_lag, const float *__restrict__ ev_rows,
+    const float *__restrict__ ev_norm, float eps, const int *__restrict__ overlap, int64_t win_cap) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float *nw = reinterpret_cast<float *>(smem);  // the new atom, L floats
+    float *win = nw + L;                          // win_cap floats: an atom's residual windows
+    __shared__ float s_den;
+    for (int64_t g = 0; g < n_groups; ++g)
+        dictionary_update_group(g, residual, sparse, N, d_work, L, order, off, ev_batch, ev_lag, ev_rows, ev_norm, eps,
+                                overlap, win_cap, nw, win, s_den);
+}
+
+// The same loop spread over the chip.  Atom g's update reads and writes only the samples under its own events, so
+// it depends on an EARLIER atom only if one of that atom's events shares a sample with one of its own.  The host
+// (mp_dictionary_levels_host) sorts the atoms into levels -- level(g) = 1 + the highest level among the earlier
+// atoms g overlaps -- and the atoms of one level, mutually disjoint and with everything they depend on finished,
+// run as one launch, one workgroup each.  Every sample still sees the same operations in the same order as in the
+// one-workgroup loop: bit-identical (tests/test_gpu_api.py::test_dictionary_update_levels_are_bit_identical).
+// Headline shape: ~400 used atoms in ~34 levels -- 34 short launches instead of a 3.2 ms single-workgroup kernel.
+__global__ __launch_bounds__(1024) void dictionary_update_level_kernel(
+    float *residual, float *sparse, int64_t N, float *d_work, int64_t L,
+    const int64_t *__restrict__ order, const int64_t *__restrict__ off, const int64_t *__restrict__ glist,
+    const int64_t *__restrict__ ev_batch, const int64_t *__restrict__ ev_lag, const float *__restrict__ ev_rows,
+    const float *__restrict__ ev_norm, float eps, const int *__restrict__ overlap, int64_t win_cap) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float *nw = reinterpret_cast<float *>(smem);
+    float *win = nw + L;
+    __shared__ float s_den;
+    dictionary_update_group(glist[blockIdx.x], residual, sparse, N, d_work, L, order, off, ev_batch, ev_lag, ev_rows,
+                            ev_norm, eps, overlap, win_cap, nw, win, s_den);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -2037,6 +2070,76 @@ int mp_dictionary_update_f32(float *residual, float *sparse_zeroed, int64_t B, i
     hipLaunchKernelGGL(dictionary_update_kernel, dim3(1), dim3(1024), lds, static_cast<hipStream_t>(stream), residual,
                        sparse_zeroed, N, dict_work, L, order, offsets, n_groups, ev_batch, ev_lag, ev_rows, ev_norm, eps,
                        overlap, win_cap > 0 ? win_cap : 0);
+    HIP_TRY(hipGetLastError());
+    return MP_OK;
+}
+
+int mp_dictionary_levels_host(const int64_t *offsets, int64_t n_groups, const int64_t *ev_batch, const int64_t *ev_lag,
+                              int64_t n_events, int64_t L, int32_t *level, int32_t *overlap, int64_t *n_levels) {
+    if (!offsets || !ev_batch || !ev_lag || !level || !overlap || !n_levels || n_groups < 0 || n_events < 0 || L <= 0)
+        return fail(MP_ERR_ARG, "mp_dictionary_levels_host: bad arguments%s");
+    if (n_groups && offsets[n_groups] != n_events) return fail(MP_ERR_ARG, "mp_dictionary_levels_host: offsets do not cover the events%s");
+    std::vector<int32_t> group((size_t)n_events);
+    for (int64_t g = 0; g < n_groups; ++g) {
+        level[g] = 0;
+        overlap[g] = 0;
+        for (int64_t e = offsets[g]; e < offsets[g + 1]; ++e) group[(size_t)e] = (int32_t)g;
+    }
+    std::vector<int64_t> idx((size_t)n_events);
+    for (int64_t e = 0; e < n_events; ++e) idx[(size_t)e] = e;
+    std::sort(idx.begin(), idx.end(), [&](int64_t a, int64_t b) {
+        return ev_batch[a] != ev_batch[b] ? ev_batch[a] < ev_batch[b] : (ev_lag[a] != ev_lag[b] ? ev_lag[a] < ev_lag[b] : a < b);
+    });
+    // pairs of events that share a sample: same segment, lags less than L apart
+    std::vector<std::pair<int32_t, int32_t>> edges;  // (later group, earlier group)
+    for (int64_t i = 0; i < n_events; ++i) {
+        const int64_t a = idx[(size_t)i];
+        for (int64_t j = i + 1; j < n_events; ++j) {
+            const int64_t b = idx[(size_t)j];
+            if (ev_batch[b] != ev_batch[a] || ev_lag[b] - ev_lag[a] >= L) break;
+            const int32_t ga = group[(size_t)a], gb = group[(size_t)b];
+            if (ga == gb) overlap[ga] = 1;
+            else edges.emplace_back(ga > gb ? ga : gb, ga > gb ? gb : ga);
+        }
+    }
+    std::sort(edges.begin(), edges.end());
+    int32_t top = -1;
+    size_t q = 0;
+    for (int64_t g = 0; g < n_groups; ++g) {  // ascending: every earlier group's level is final
+        int32_t lv = 0;
+        for (; q < edges.size() && edges[q].first == g; ++q) lv = std::max(lv, level[edges[q].second] + 1);
+        level[g] = lv;
+        top = std::max(top, lv);
+    }
+    *n_levels = (int64_t)top + 1;
+    return MP_OK;
+}
+
+int mp_dictionary_update_levels_f32(float *residual, float *sparse_zeroed, int64_t B, int64_t N, float *dict_work,
+                                    int64_t A, int64_t L, const int64_t *order, const int64_t *offsets, int64_t n_groups,
+                                    const int64_t *ev_batch, const int64_t *ev_lag, const float *ev_rows,
+                                    const float *ev_norm, float eps, const int *overlap, const int64_t *group_list,
+                                    const int64_t *level_offsets_host, int64_t n_levels, void *stream) {
+    if (n_groups == 0 || n_levels == 0) return MP_OK;
+    if (!residual || !sparse_zeroed || !dict_work || !order || !offsets || !ev_batch || !ev_lag || !ev_rows || !ev_norm ||
+        !overlap || !group_list || !level_offsets_host || B <= 0 || N <= 0 || A <= 0 || L <= 0 || n_groups < 0 || n_levels < 0)
+        return fail(MP_ERR_ARG, "mp_dictionary_update_levels_f32: bad arguments%s");
+    if (level_offsets_host[0] != 0 || level_offsets_host[n_levels] != n_groups)
+        return fail(MP_ERR_ARG, "mp_dictionary_update_levels_f32: level offsets do not cover the groups%s");
+    if ((size_t)L * sizeof(float) > 150 * 1024) return fail(MP_ERR_UNSUPPORTED, "mp_dictionary_update_levels_f32: atom too long for LDS%s");
+    const int64_t win_cap = (int64_t)((144 * 1024 - (size_t)L * sizeof(float)) / sizeof(float));
+    const size_t lds = ((size_t)L + (size_t)(win_cap > 0 ? win_cap : 0)) * sizeof(float);
+    if (lds > 64 * 1024)
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(dictionary_update_level_kernel),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    for (int64_t lv = 0; lv < n_levels; ++lv) {
+        const int64_t g0 = level_offsets_host[lv], g1 = level_offsets_host[lv + 1];
+        if (g1 < g0) return fail(MP_ERR_ARG, "mp_dictionary_update_levels_f32: level offsets not ascending%s");
+        if (g1 == g0) continue;
+        hipLaunchKernelGGL(dictionary_update_level_kernel, dim3((unsigned)(g1 - g0)), dim3(1024), lds,
+                           static_cast<hipStream_t>(stream), residual, sparse_zeroed, N, dict_work, L, order, offsets,
+                           group_list + g0, ev_batch, ev_lag, ev_rows, ev_norm, eps, overlap, win_cap > 0 ? win_cap : 0);
+    }
     HIP_TRY(hipGetLastError());
     return MP_OK;
 }

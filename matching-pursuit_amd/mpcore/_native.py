@@ -40,7 +40,8 @@ EXPORTS = (
     "mp_feature_map_f32", "mp_scatter_f32", "mp_scatter_rows_f32", "mp_gather_sum_f32",
     "mp_profile_enable", "mp_profile_read", "mp_fft_c2c_f32", "mp_encode_conv_f32", "mp_tune",
     "mp_dictionary_update_f32", "mp_lcn_workspace_bytes", "mp_encode_lcn_f32", "mp_conv_model_backward_f32",
-    "mp_stream_pair_ratio", "mp_init_streams", "mp_audit_read",
+    "mp_stream_pair_ratio", "mp_init_streams", "mp_audit_read", "mp_dictionary_levels_host",
+    "mp_dictionary_update_levels_f32",
 )
 
 
@@ -86,6 +87,9 @@ def lib():
         L.mp_dictionary_update_f32.argtypes = [vp, vp, i64, i64, vp, i64, i64, vp, vp, i64, vp, vp, vp, vp,
                                                ctypes.c_float, vp, vp]
         L.mp_fft_c2c_f32.argtypes = [vp, vp, ctypes.c_int, i64, ctypes.c_int, vp, vp]
+        L.mp_dictionary_levels_host.argtypes = [vp, i64, vp, vp, i64, i64, vp, vp, ctypes.POINTER(i64)]
+        L.mp_dictionary_update_levels_f32.argtypes = [vp, vp, i64, i64, vp, i64, i64, vp, vp, i64, vp, vp, vp, vp,
+                                                      ctypes.c_float, vp, vp, vp, i64, vp]
         L.mp_init_streams.argtypes = [vp]
         L.mp_audit_read.argtypes = [ctypes.POINTER(ctypes.c_float), ctypes.POINTER(i64),
                                     ctypes.POINTER(ctypes.c_float), ctypes.POINTER(i64)]
@@ -452,10 +456,29 @@ def gather_sum(x, batch, lag, L):
     return out
 
 
+def dictionary_levels(offsets, ev_batch, ev_lag, L):
+    """mp_dictionary_levels_host on HOST arrays (numpy / CPU tensors, int64): -> (level [G] int32, overlap [G] int32,
+    n_levels).  level[g] = 0 if group g overlaps no earlier group, else 1 + the highest level among those it overlaps."""
+    import numpy as np
+    offsets = np.ascontiguousarray(offsets, dtype=np.int64)
+    ev_batch = np.ascontiguousarray(ev_batch, dtype=np.int64)
+    ev_lag = np.ascontiguousarray(ev_lag, dtype=np.int64)
+    G = int(offsets.shape[0]) - 1
+    level = np.zeros(max(G, 1), dtype=np.int32)
+    overlap = np.zeros(max(G, 1), dtype=np.int32)
+    n_levels = ctypes.c_int64(0)
+    _check(lib().mp_dictionary_levels_host(offsets.ctypes.data, G, ev_batch.ctypes.data, ev_lag.ctypes.data,
+                                           int(ev_batch.shape[0]), int(L), level.ctypes.data, overlap.ctypes.data,
+                                           ctypes.byref(n_levels)), "mp_dictionary_levels_host")
+    return level[:G], overlap[:G], int(n_levels.value)
+
+
 def dictionary_update(residual, d_work, order, offsets, ev_batch, ev_lag, ev_rows, ev_norm, eps=1e-8,
-                      one_by_one=False):
-    """mp_dictionary_update_f32: the atom-by-atom loop of dictionary_learning_step in one launch.
-    residual [B, N] and d_work [A, L] are updated in place."""
+                      one_by_one=False, host_events=None):
+    """The atom-by-atom loop of dictionary_learning_step; residual [B, N] and d_work [A, L] are updated in place.
+    host_events = (offsets, ev_batch, ev_lag) as host arrays: the loop is spread over the chip, one launch per
+    dependency level and one workgroup per atom (mp_dictionary_update_levels_f32); without them, or with
+    one_by_one (tests), it runs as one launch of one workgroup (mp_dictionary_update_f32).  Bit-identical."""
     _require_cuda(residual, d_work)
     assert residual.dtype == torch.float32 and residual.is_contiguous() and d_work.is_contiguous()
     dev = residual.device
@@ -465,9 +488,27 @@ def dictionary_update(residual, d_work, order, offsets, ev_batch, ev_lag, ev_row
     ev_batch, ev_lag = _i64(ev_batch, dev), _i64(ev_lag, dev)
     ev_rows, ev_norm = _f32(ev_rows), _f32(ev_norm)
     sparse = torch.zeros_like(residual)
+    n_groups, n_events = order.numel(), ev_batch.numel()
+    if host_events is not None and not one_by_one and n_groups > 0:
+        import numpy as np
+        level, overlap_h, n_levels = dictionary_levels(*host_events, L)
+        glist = np.argsort(level, kind="stable").astype(np.int64)          # groups by level, ascending inside a level
+        level_off = np.zeros(n_levels + 1, dtype=np.int64)
+        level_off[1:] = np.cumsum(np.bincount(level, minlength=n_levels))
+        packed = torch.from_numpy(np.concatenate([glist, overlap_h.astype(np.int64)])).to(dev)   # one small H2D copy
+        glist_d = packed[:n_groups]
+        overlap = packed[n_groups:].to(torch.int32)
+        with torch.cuda.device(dev):
+            rc = lib().mp_dictionary_update_levels_f32(
+                _ptr(residual), _ptr(sparse), B, N, _ptr(d_work), A, L, _ptr(order), _ptr(offsets), n_groups,
+                _ptr(ev_batch), _ptr(ev_lag), _ptr(ev_rows), _ptr(ev_norm), ctypes.c_float(eps), _ptr(overlap),
+                _ptr(glist_d), level_off.ctypes.data, n_levels, _stream(residual))
+        _check(rc, "mp_dictionary_update_levels_f32")
+        for t in (sparse, packed, overlap):
+            t.record_stream(torch.cuda.current_stream(dev))
+        return n_levels
     # which atoms have two events sharing a sample (same segment, lags < L apart)?  Sort the events by
     # (group, segment, lag) and look at neighbours -- a few small device operations, no synchronisation
-    n_groups, n_events = order.numel(), ev_batch.numel()
     overlap = torch.zeros(max(n_groups, 1), dtype=torch.int32, device=dev)
     if one_by_one:  # (tests) every atom's events one after another, as if they all overlapped
         overlap.fill_(1)

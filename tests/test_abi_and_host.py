@@ -164,3 +164,39 @@ def test_hot_kernels_keep_their_register_budget():
         assert r["spill"] == 0 and r["vgpr"] <= 128, (name, r)
     persistent = {n: r for n, r in res.items() if "correlate_persistent_kernel" in n}
     assert persistent and all(r["spill"] == 0 for r in persistent.values())
+
+
+def test_dictionary_levels_host_helper_matches_brute_force():
+    """mp_dictionary_levels_host (host arrays only, no GPU): level[g] = 0 if group g shares no sample with an earlier
+    group, else 1 + the highest level among the earlier groups it overlaps; overlap[g] flags two events of the same
+    group sharing a sample."""
+    rng = np.random.default_rng(12)
+    for trial in range(6):
+        B, N, L = int(rng.integers(1, 6)), int(rng.integers(200, 3000)), int(rng.choice([1, 16, 100, 257]))
+        G = int(rng.integers(1, 40))
+        counts = rng.integers(1, 7, G)
+        offsets = np.concatenate([[0], np.cumsum(counts)]).astype(np.int64)
+        E = int(offsets[-1])
+        ev_batch = rng.integers(0, B, E).astype(np.int64)
+        ev_lag = rng.integers(0, N, E).astype(np.int64)
+        level, overlap, n_levels = nat.dictionary_levels(offsets, ev_batch, ev_lag, L)
+        group = np.repeat(np.arange(G), counts)
+        want_level = np.zeros(G, dtype=np.int64)
+        want_overlap = np.zeros(G, dtype=np.int64)
+        touch = lambda a, b: ev_batch[a] == ev_batch[b] and abs(int(ev_lag[a]) - int(ev_lag[b])) < L
+        for g in range(G):
+            mine = np.nonzero(group == g)[0]
+            for i in mine:
+                for j in mine:
+                    if i < j and touch(i, j):
+                        want_overlap[g] = 1
+            lv = 0
+            for h in range(g):
+                theirs = np.nonzero(group == h)[0]
+                if any(touch(i, j) for i in mine for j in theirs):
+                    lv = max(lv, want_level[h] + 1)
+            want_level[g] = lv
+        assert np.array_equal(level, want_level) and np.array_equal(overlap, want_overlap)
+        assert n_levels == int(want_level.max()) + 1
+    level, overlap, n_levels = nat.dictionary_levels(np.zeros(1, dtype=np.int64), np.zeros(0), np.zeros(0), 8)
+    assert n_levels == 0 and level.shape == (0,)

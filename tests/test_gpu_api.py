@@ -570,6 +570,38 @@ def test_event_form_of_the_stft_loss_equals_the_dense_form():
     assert (model.atoms.grad - g_dense).abs().max().item() <= 2e-4 * g_dense.abs().max().item()
 
 
+def test_dictionary_update_levels_are_bit_identical(oracle):
+    """The dictionary update spread over the chip (one launch per dependency level, one workgroup per atom:
+    mp_dictionary_update_levels_f32) against the one-workgroup loop in its two forms (events of an atom at once /
+    one by one) bit for bit, and against the oracle -- on a batch dense enough that most atoms depend on others."""
+    from mpcore import _native as nat
+    A, L, N, B, K = 96, 128, 3000, 12, 24
+    d = synth.make_dictionary(A, L, seed=91)
+    x = synth.make_segments(B, N, d, n_events=30, seed=92)
+    xt, dt = torch.from_numpy(x).to(DEV)[:, None, :], torch.from_numpy(d).to(DEV)
+    seen = {}
+    real = nat.dictionary_update
+
+    def run(**force):
+        def spy(*args, **kw):
+            kw.update(force)
+            seen[tuple(sorted(force))] = real(*args, **kw)
+            return seen[tuple(sorted(force))]
+        nat.dictionary_update = spy
+        try:
+            return mp.dictionary_learning_step(xt, dt, n_steps=K)
+        finally:
+            nat.dictionary_update = real
+
+    levels = run()
+    single = run(host_events=None)
+    slow = run(one_by_one=True)
+    assert isinstance(seen[()], int) and 2 <= seen[()] < 200       # the level form ran, with a real dependency depth
+    assert torch.equal(levels, single) and torch.equal(levels, slow)
+    want = oracle.dictionary_learning_step(x, d, K)
+    assert np.abs(levels.cpu().numpy() - want).max() <= 2e-6
+
+
 def test_dictionary_update_fast_path_is_bit_identical_and_overlaps_are_detected(oracle):
     """mp_dictionary_update_f32 applies an atom's events all at once when none of them share a sample, one by one
     (staged in the scratch map, as the reference's dense tensors do) when they do.  A batch where one atom is
