@@ -67,6 +67,9 @@ extern "C" {
 #define MP_FLAG_FFT_NO_QUARTER 8192 /* MP_PATH_FFT: segments of <= 16384 cells through scan+refine / select-B instead
                                        of the one-kernel quarter-cell select (default when the batch is split)    */
 #define MP_FLAG_FFT_QUARTER 16384   /* MP_PATH_FFT: the quarter-cell select also when the batch stays on one stream */
+#define MP_FLAG_FFT_PERSISTENT 65536 /* MP_PATH_FFT: steps 1 .. K-1 of the whole batch in ONE launch of resident workgroups that
+                                        pull screen tasks and run a segment's select when its last task completes
+                                        (csrc/mppersist.inc); shapes it does not cover fall back to the other forms  */
 #define MP_FLAG_GROUPS_SHIFT 20
 #define MP_FLAG_GROUPS(n) (((n) & 7) << MP_FLAG_GROUPS_SHIFT) /* this call: n (2..4) sub-batches where the batch is split */
 #define MP_FLAG_NO_PERSISTENT 8 /* one workgroup per 4 cells instead of machine-sized persistent grid */

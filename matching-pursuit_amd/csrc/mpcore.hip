@@ -1078,6 +1078,8 @@ __global__ __launch_bounds__(1024) void dictionary_update_level_kernel(
 // ------------------------------------------------------------------------------------------------
 #include "mpfft.inc"
 
+constexpr int MP_FLAG_FFT_PERSISTENT_BIT = 65536;  // (= MP_FLAG_FFT_PERSISTENT, include/mpcore.h)
+
 struct Workspace {
     float *res;
     float *img;
@@ -1092,10 +1094,13 @@ struct Workspace {
     float *subk;    // per-quarter-cell screen maxima [B][cells][SUBCELLS]; only for <= QUARTER_MAX_CELLS
     unsigned *bsum; // per-block (upper, lower) bound summaries [B][NBLK][2]; used for >= FUSED_MIN_CELLS
     u64 *ekeys;
+    char *pctl;     // persistent schedule: control block + queue entries (mppersist.inc); nullptr if the shape is not eligible
+    cpx *xrec;      // ... and the per-(segment, step) window records
     size_t bytes;
 };
 
-Workspace carve(const Geom &g, int path, char *base) {
+// K: steps of the encode (sizes the persistent schedule's per-step records; 0 = that schedule is not carved)
+Workspace carve(const Geom &g, int path, char *base, int K = 0) {
     Workspace w;
     size_t off = 0;
     auto take = [&](size_t n) {
@@ -1117,6 +1122,8 @@ Workspace carve(const Geom &g, int path, char *base) {
     w.dscale = nullptr;
     w.subk = nullptr;
     w.bsum = nullptr;
+    w.pctl = nullptr;
+    w.xrec = nullptr;
     if (path == MP_PATH_FFT) {
         FftGeom f;
         if (make_fft_geom(g, &f)) {
@@ -1145,6 +1152,14 @@ Workspace carve(const Geom &g, int path, char *base) {
             w.dscale = reinterpret_cast<float *>(base + o_ds);
             w.bsum = reinterpret_cast<unsigned *>(base + o_bs);
             if (quarters) w.subk = reinterpret_cast<float *>(base + o_sk);
+            // persistent schedule (mppersist.inc): queue + one window record per (segment, step >= 2)
+            if (quarters && !f.split && f.logM >= 10 && f.logM <= 12 && K >= 2) {
+                const size_t qn = (size_t)g.B * (K - 1) + 2;
+                size_t o_pc = take(128 + qn * 64);
+                size_t o_xr = take((size_t)g.B * (K > 2 ? K - 2 : 0) * ((size_t)f.M + 16) * sizeof(cpx));
+                w.pctl = base + o_pc;
+                w.xrec = reinterpret_cast<cpx *>(base + o_xr);
+            }
         }
     }
     w.res = reinterpret_cast<float *>(base + o_res);
@@ -1589,6 +1604,8 @@ int fft_iteration(const Geom &g, const Workspace &w, const float *du, int K, int
     return MP_OK;
 }
 
+#include "mppersist.inc"
+
 // ---- sub-batches on forked streams -----------------------------------------------------------------
 constexpr int MAX_GROUPS = 4;
 struct StreamPool {
@@ -1711,7 +1728,7 @@ const char *mp_last_error(void) { return g_err; }
 
 size_t mp_workspace_bytes(int64_t B, int64_t N, int64_t A, int64_t L, int K, int path) {
     if (check_shape(B, N, A, L, K) != MP_OK) return 0;
-    if (path == MP_PATH_FFT) return carve(make_geom_for(B, N, A, L, path, 0), path, nullptr).bytes;
+    if (path == MP_PATH_FFT) return carve(make_geom_for(B, N, A, L, path, 0), path, nullptr, K).bytes;
     size_t b64 = carve(make_geom(B, N, A, L, 64), path, nullptr).bytes;
     size_t b32 = carve(make_geom(B, N, A, L, 32), path, nullptr).bytes;
     return b64 > b32 ? b64 : b32;
@@ -1771,7 +1788,7 @@ static int encode_impl(const float *signal, int64_t B, int64_t N, const float *d
     if (K > 0 && (!out_atom || !out_lag || !out_gain)) return fail(MP_ERR_ARG, "null output%s");
     if (reinterpret_cast<uintptr_t>(workspace) % 256) return fail(MP_ERR_WORKSPACE, "workspace not 256-byte aligned%s");
     Geom g = make_geom_for(B, N, A, L, path, flags);
-    Workspace w = carve(g, path, static_cast<char *>(workspace));
+    Workspace w = carve(g, path, static_cast<char *>(workspace), K);
     if (w.bytes > workspace_bytes) return fail(MP_ERR_WORKSPACE, "workspace too small%s");
     hipStream_t st = static_cast<hipStream_t>(stream);
 
@@ -1808,6 +1825,30 @@ static int encode_impl(const float *signal, int64_t B, int64_t N, const float *d
     // schedule; -4 % at the config-4 shape, whose screens fill the GPU on their own.  Default for MP_PATH_FFT:
     // four sub-batches from 48 segments up when a segment has < 65536 cells (MP_FLAG_NO_OVERLAP turns it off),
     // opt-in elsewhere (MP_FLAG_OVERLAP).  Only on streams seen to run side by side (stream_pool).
+    // The persistent schedule (mppersist.inc): step 0 as separate kernels (full-pass screen, quarter select), then
+    // steps 1 .. K-1 of the whole batch in one launch of resident workgroups.
+    if (path == MP_PATH_FFT && (flags & MP_FLAG_FFT_PERSISTENT_BIT)) {
+        FftGeom f;
+        if (make_fft_geom(g, &f) && persist_eligible(g, f, w, K)) {
+            const int f0 = (flags & ~(MP_FLAG_FFT_NO_QUARTER | MP_FLAG_FFT_FUSED | MP_FLAG_FFT_UNFUSED | MP_FLAG_REFINE_MFMA |
+                                      MP_FLAG_FFT_SIMPLE)) | MP_FLAG_FFT_QUARTER | MP_FLAG_INTERNAL_ONE_STREAM;
+            g_prof.arm(0);
+            if ((rc = fft_iteration(g, w, dict_unit, K, 0, f0, out_atom, out_lag, out_gain, rule, st))) return rc;
+            g_prof.begin(PROF_CORR_INC, st);  // (one span around the whole launch: steps 1 .. K-1)
+            rc = launch_persistent(g, f, w, dict_unit, rule, K, fft_tau(f.logM).tau, out_atom, out_lag, out_gain, st);
+            g_prof.end(st);
+            if (rc) return rc;
+            hipLaunchKernelGGL(persist_error_kernel, dim3((unsigned)((B + 255) / 256)), dim3(256), 0, st, w.pctl, w.overflow, (int)B);
+            hipLaunchKernelGGL(fft_mark_overflow_kernel, dim3((unsigned)B), dim3(64), 0, st, w.overflow, out_gain, K);
+            HIP_TRY(hipGetLastError());
+            if (out_residual) {
+                dim3 grid((unsigned)((N + 255) / 256 < 1024 ? (N + 255) / 256 : 1024), (unsigned)B);
+                hipLaunchKernelGGL(copy_residual_kernel, grid, dim3(256), 0, st, w.res, N, g.Ns, out_residual, rule.lead);
+                HIP_TRY(hipGetLastError());
+            }
+            return MP_OK;
+        }
+    }
     int n_groups = 1;
     if (K > 0 && !(flags & MP_FLAG_NO_OVERLAP) &&
         (((flags & MP_FLAG_OVERLAP) && B >= 8) ||

@@ -34,6 +34,7 @@ MP_FLAG_FFT_QUARTER = 16384
 MP_FLAG_FFT_UNFUSED = 512
 MP_FLAG_FFT_FUSED = 1024
 MP_FLAG_OVERLAP = 2048
+MP_FLAG_FFT_PERSISTENT = 65536
 
 EXPORTS = (
     "mp_version", "mp_last_error", "mp_workspace_bytes", "mp_unit_norm_f32", "mp_encode_f32",
