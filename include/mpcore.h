@@ -101,6 +101,10 @@ int mp_profile_enable(int every);
 #define MP_TUNE_SCREEN_PPS 2
 #define MP_TUNE_GROUPS 3
 #define MP_TUNE_AUDIT 4
+#define MP_TUNE_PERSIST_STAGGER 7 /* MP_FLAG_FFT_PERSISTENT: 10-ns ticks between the releases of the batch's initial queue
+                                     entries (< 0 = heuristic: one 46 us cycle spread over the batch)                */
+#define MP_TUNE_PERSIST_SHARDS 6 /* MP_FLAG_FFT_PERSISTENT: number of ticket counters the screen workers are split over
+                                    (0 = heuristic: one per ~512 workers)                                          */
 int mp_tune(int key, double value);
 int mp_profile_read(double *ms, int64_t *count);
 
@@ -190,6 +194,12 @@ float mp_stream_pair_ratio(int q0, int q1);
  * encode into a hipGraph if the graph should contain sub-batches.  Returns the number of internal streams seen
  * to run side by side (>= 1; sub-batches need >= 2), or a negative error (e.g. `stream` is being captured). */
 int mp_init_streams(void *stream);
+
+/* Debug: statistics of the last MP_FLAG_FFT_PERSISTENT launch on the current device, summed over its workgroups --
+ * out16[0..2] = 100 MHz wall-clock ticks spent idle (polling the queue), in screen tasks, in selects; [3..5] = tasks,
+ * selects, polls; [6] = error flag, [7] = segments finished; [8..12] = ticks of the selects' phases (acquire, scan,
+ * quarters + chains, event + next window, transform + stores), [13] = selects counted.  Synchronises the device. */
+int mp_persist_stats(uint64_t *out16);
 
 /* Debug (MP_TUNE_AUDIT): the largest |screen - exact| / eps over all cells audited since the last read, their
  * number, the same for quarter-cell maxima, and how many exceeded 1 (must be 0).  Synchronises the device;

@@ -1155,7 +1155,7 @@ Workspace carve(const Geom &g, int path, char *base, int K = 0) {
             // persistent schedule (mppersist.inc): queue + one window record per (segment, step >= 2)
             if (quarters && !f.split && f.logM >= 10 && f.logM <= 12 && K >= 2) {
                 const size_t qn = (size_t)g.B * (K - 1) + 2;
-                size_t o_pc = take(128 + qn * 64);
+                size_t o_pc = take(256 + 512 * 64 + qn * 128);  // PersistCtl + group words + PersistEntry[qn] (mppersist.inc)
                 size_t o_xr = take((size_t)g.B * (K > 2 ? K - 2 : 0) * ((size_t)f.M + 16) * sizeof(cpx));
                 w.pctl = base + o_pc;
                 w.xrec = reinterpret_cast<cpx *>(base + o_xr);
@@ -1466,6 +1466,7 @@ int fft_iteration(const Geom &g, const Workspace &w, const float *du, int K, int
     const bool fused_tail = (fused && f.logM >= 10) || b_tail || quarter;
     // (kept up to date by fft_screen_kernel only: not with the plain radix-4 screen)
     unsigned *bsum = (fused && n_cells > QUARTER_MAX_CELLS && f.logM >= 10 && !(flags & MP_FLAG_FFT_SIMPLE)) ? w.bsum : nullptr;
+    if ((flags & MP_FLAG_FFT_PERSISTENT_BIT) && quarter) bsum = w.bsum;  // step 0 of the persistent schedule builds them too
     {
         const int *dirty = k == 0 ? nullptr : w.dirty;
         const int nw = k == 0 ? f.NW : 1;
@@ -1528,7 +1529,7 @@ int fft_iteration(const Geom &g, const Workspace &w, const float *du, int K, int
         })
         g_prof.end(st);
         HIP_TRY(hipGetLastError());
-        if (audit_on.load(std::memory_order_relaxed)) {  // debug: how much of its bound did that screen use?
+        if (audit_on.load(std::memory_order_relaxed) & 1) {  // debug: how much of its bound did that screen use?
             const float *subk_a = (quarter && !f.split) ? w.subk : nullptr;
             hipLaunchKernelGGL(fft_audit_kernel, dim3(g.NAT, k == 0 ? g.NBLK : g.MAXC, (unsigned)g.B), dim3(64), 0, st,
                                w.res, du, dirty, w.keys, w.ceps, subk_a, g.N, g.A, g.L, g.Ns, g.NBLK, g.NAT);
@@ -1544,7 +1545,7 @@ int fft_iteration(const Geom &g, const Workspace &w, const float *du, int K, int
                 hipLaunchKernelGGL(fft_select_quarter_kernel<LQ>, dim3((unsigned)g.B), dim3(1024), lds_q, st, w.keys,
                                    w.ceps, w.subk, n_cells, w.res, du, w.dirty, w.overflow, out_atom, out_lag, out_gain,
                                    g.N, g.A, g.L, g.Ns, g.NBLK, g.NAT, K, k, rule.du_sub, rule.shift, rule.square, w.tw,
-                                   w.xspec, w.wnorm, f.NW, (const float *)w.dscale);
+                                   w.xspec, w.wnorm, f.NW, (const float *)w.dscale, bsum);
             })
         } else if (fused) {
             const size_t lds_chain = (size_t)(round_up(g.L, 64) + 128) * sizeof(float);
@@ -1738,7 +1739,9 @@ int mp_tune(int key, double value) {
     if (key == MP_TUNE_TAU && value >= 0.0) { tau_override.store((float)value); return MP_OK; }  // 0: back to the model
     if (key == MP_TUNE_SCREEN_PPS) { screen_pps_override.store((int)value); return MP_OK; }
     if (key == MP_TUNE_GROUPS && value >= 2 && value <= MAX_GROUPS) { overlap_groups.store((int)value); return MP_OK; }
-    if (key == MP_TUNE_AUDIT) { audit_on.store(value != 0.0); return MP_OK; }
+    if (key == MP_TUNE_AUDIT) { audit_on.store((int)value); return MP_OK; }  // bit 0: screen audit; bit 1: persistent-schedule latencies
+    if (key == MP_TUNE_PERSIST_SHARDS && value >= 0) { persist_shards.store((int)value); return MP_OK; }
+    if (key == MP_TUNE_PERSIST_STAGGER) { persist_stagger.store((int)value); return MP_OK; }
     return fail(MP_ERR_ARG, "mp_tune: unknown key or bad value%s");
 }
 
@@ -2214,6 +2217,18 @@ int mp_audit_read(float *max_ratio, int64_t *cells, float *max_quarter_ratio, in
     if (cells) *cells = (int64_t)h[1];
     if (max_quarter_ratio) *max_quarter_ratio = r2;
     if (over_bound) *over_bound = (int64_t)h[3];
+    return MP_OK;
+}
+
+int mp_persist_stats(uint64_t *out8 /* [16] */) {
+    if (!out8) return fail(MP_ERR_ARG, "mp_persist_stats: null output%s");
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_persist_stats), 8 * sizeof(uint64_t)));
+    {   // the selects' phase ticks behind them: [8..12] acquire, scan, quarters + chains, event + window, transform + stores; [13] selects
+        const uint64_t zero[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        HIP_TRY(hipMemcpyFromSymbol(out8 + 8, HIP_SYMBOL(g_persist_phase), 8 * sizeof(uint64_t)));
+        HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(g_persist_phase), zero, sizeof(zero)));
+    }
     return MP_OK;
 }
 

@@ -27,6 +27,8 @@ MP_TUNE_TAU = 1
 MP_TUNE_SCREEN_PPS = 2
 MP_TUNE_GROUPS = 3
 MP_TUNE_AUDIT = 4
+MP_TUNE_PERSIST_SHARDS = 6
+MP_TUNE_PERSIST_STAGGER = 7
 MP_FLAG_GROUPS_SHIFT = 20
 MP_FLAG_NO_OVERLAP = 4096
 MP_FLAG_FFT_NO_QUARTER = 8192
@@ -42,7 +44,7 @@ EXPORTS = (
     "mp_profile_enable", "mp_profile_read", "mp_fft_c2c_f32", "mp_encode_conv_f32", "mp_tune",
     "mp_dictionary_update_f32", "mp_lcn_workspace_bytes", "mp_encode_lcn_f32", "mp_conv_model_backward_f32",
     "mp_stream_pair_ratio", "mp_init_streams", "mp_audit_read", "mp_dictionary_levels_host",
-    "mp_dictionary_update_levels_f32",
+    "mp_dictionary_update_levels_f32", "mp_persist_stats",
 )
 
 
@@ -140,6 +142,18 @@ def init_streams(device=None):
     if n < 0:
         raise NativeError(f"mp_init_streams failed (rc={n}): {lib().mp_last_error().decode()}")
     return int(n)
+
+
+def persist_stats():
+    """mp_persist_stats: dict of the last persistent launch's statistics (ticks of 10 ns summed over workgroups)."""
+    buf = (ctypes.c_uint64 * 16)()
+    _check(lib().mp_persist_stats(buf), "mp_persist_stats")
+    k = ("idle_ticks", "task_ticks", "select_ticks", "tasks", "selects", "polls", "error", "finished")
+    out = {n: int(buf[i]) for i, n in enumerate(k)}
+    n = max(int(buf[13]), 1)
+    out["select_phase_us"] = {p: round(int(buf[8 + i]) / 100.0 / n, 2)
+                              for i, p in enumerate(("acquire", "scan", "chains", "event_window", "transform_stores"))}
+    return out
 
 
 def audit_read():

@@ -46,4 +46,9 @@ if mode in ("all", "time") and ok:
             if ref is None: ref = out
             same = all(torch.equal(a, b) for a, b in zip(out, ref))
             print(f"B{B:4d} {name:24s} {float(np.median(ts)) * 1e3:8.3f} ms {B * K / float(np.median(ts)):9.0f} seg-it/s  same={same}", flush=True)
+            if name == "persistent":
+                st = nat.persist_stats()
+                print("      ", st, f"| per task {st['task_ticks'] / max(st['tasks'], 1) / 100:.1f} us, per select "
+                      f"{st['select_ticks'] / max(st['selects'], 1) / 100:.1f} us, idle per workgroup "
+                      f"{st['idle_ticks'] / 2048 / 100:.0f} us", flush=True)
 sys.exit(0 if ok else 1)

@@ -25,7 +25,7 @@ if AUDIT:
 audit_worst = dict(max_ratio=0.0, max_quarter_ratio=0.0, cells=0, over_bound=0)
 paths = [("fft", nat.MP_PATH_FFT, 0), ("fft_one_stream", nat.MP_PATH_FFT, nat.MP_FLAG_NO_OVERLAP),
          ("fft_scan_refine", nat.MP_PATH_FFT, nat.MP_FLAG_FFT_NO_QUARTER), ("fft_quarter", nat.MP_PATH_FFT, nat.MP_FLAG_FFT_QUARTER), ("fft_fused", nat.MP_PATH_FFT, nat.MP_FLAG_FFT_FUSED),
-         ("incremental", nat.MP_PATH_INCREMENTAL, 0)]
+         ("fft_persistent", nat.MP_PATH_FFT, nat.MP_FLAG_FFT_PERSISTENT), ("incremental", nat.MP_PATH_INCREMENTAL, 0)]
 bad = 0
 marked = 0
 for case in range(n_cases):

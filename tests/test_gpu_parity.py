@@ -40,6 +40,7 @@ PATHS = [
     ("incremental_nonpersistent", nat.MP_PATH_INCREMENTAL, nat.MP_FLAG_NO_PERSISTENT),
     ("direct_nonpersistent_nodma", nat.MP_PATH_DIRECT, nat.MP_FLAG_NO_PERSISTENT | nat.MP_FLAG_NO_DMA),
     ("incremental_ta64_nodma", nat.MP_PATH_INCREMENTAL, nat.MP_FLAG_TA64 | nat.MP_FLAG_NO_DMA),
+    ("fft_persistent", nat.MP_PATH_FFT, nat.MP_FLAG_FFT_PERSISTENT),   # one launch for steps 1 .. K-1 (csrc/mppersist.inc)
 ]
 
 # name: (A, L, N, B, K, n_events, seed)
@@ -725,3 +726,36 @@ def test_config3_full_size_default_schedule():
     inc = nat.encode(x[:4], du, 16, path=nat.MP_PATH_INCREMENTAL)
     torch.cuda.synchronize()
     assert torch.equal(inc[0], atom[:4, :16]) and torch.equal(inc[1], lag[:4, :16]) and torch.equal(inc[2], gain[:4, :16])
+
+
+def test_persistent_schedule_full_size_and_statistics(oracle):
+    """MP_FLAG_FFT_PERSISTENT at BASELINE configs[1] size: steps 1 .. K-1 of all 64 segments in ONE launch of
+    resident workgroups (a queue of screen tasks, select workers, hand-offs inside the launch) -- the same events
+    as the launch-per-step schedule bit for bit, every segment finished, no bounded wait given up; also on the
+    convolution model (raw atoms, v^2 update) and with more segments than select workers."""
+    A, L, N, B, K = 512, 512, 32768, 64, 64
+    d = synth.make_dictionary(A, L, seed=1000)
+    x_host = synth.make_segments(B, N, d, n_events=3 * K, seed=1002)
+    x = torch.from_numpy(x_host).to(DEV)
+    du = nat.unit_norm(torch.from_numpy(d).to(DEV))
+    ref = nat.encode(x, du, K, path=nat.MP_PATH_FFT, flags=nat.MP_FLAG_NO_OVERLAP)
+    for _ in range(3):   # (hand-offs are timing dependent: more than one run)
+        out = nat.encode(x, du, K, path=nat.MP_PATH_FFT, flags=nat.MP_FLAG_FFT_PERSISTENT)
+        torch.cuda.synchronize()
+        assert all(torch.equal(p, q) for p, q in zip(out, ref))
+        st = nat.persist_stats()
+        assert st["error"] == 0 and st["finished"] == B and st["selects"] == B * (K - 1)
+        assert st["tasks"] * 8 == B * (K - 1) * (A // 2)           # every atom pair of every step screened once (8 pairs a task)
+    want = oracle.encode(x_host[:4], du.cpu().numpy(), 16)
+    assert np.array_equal(out[0][:4, :16].cpu().numpy(), want["atom"]) and np.array_equal(out[2][:4, :16].cpu().numpy(), want["gain"])
+    # more segments than select workers, an uneven tile count, the convolution model's update rule
+    d2 = synth.make_dictionary(200, 200, seed=7)
+    x2 = torch.from_numpy(synth.make_segments(150, 9000, d2, n_events=20, seed=8)).to(DEV)
+    du2 = nat.unit_norm(torch.from_numpy(d2).to(DEV))
+    for conv in (False, True):
+        dd = du2 * 1.3 if conv else du2
+        a = nat.encode(x2, dd, 9, path=nat.MP_PATH_FFT, flags=nat.MP_FLAG_NO_OVERLAP, conv_model=conv)
+        b = nat.encode(x2, dd, 9, path=nat.MP_PATH_FFT, flags=nat.MP_FLAG_FFT_PERSISTENT, conv_model=conv)
+        torch.cuda.synchronize()
+        assert all(torch.equal(p, q) for p, q in zip(a, b))
+        assert nat.persist_stats()["finished"] == 150
