@@ -753,9 +753,11 @@ def test_persistent_schedule_full_size_and_statistics(oracle):
     x2 = torch.from_numpy(synth.make_segments(150, 9000, d2, n_events=20, seed=8)).to(DEV)
     du2 = nat.unit_norm(torch.from_numpy(d2).to(DEV))
     for conv in (False, True):
-        dd = du2 * 1.3 if conv else du2
+        dd = du2 * 0.2 if conv else du2      # (the model's raw atoms are small: its v^2 update diverges for atoms of norm > 1)
         a = nat.encode(x2, dd, 9, path=nat.MP_PATH_FFT, flags=nat.MP_FLAG_NO_OVERLAP, conv_model=conv)
         b = nat.encode(x2, dd, 9, path=nat.MP_PATH_FFT, flags=nat.MP_FLAG_FFT_PERSISTENT, conv_model=conv)
+        inc = nat.encode(x2, dd, 9, path=nat.MP_PATH_INCREMENTAL, conv_model=conv)
         torch.cuda.synchronize()
-        assert all(torch.equal(p, q) for p, q in zip(a, b))
+        assert not torch.isnan(a[3]).any()
+        assert all(torch.equal(p, q) for p, q in zip(a, b)) and all(torch.equal(p, q) for p, q in zip(inc, b))
         assert nat.persist_stats()["finished"] == 150
