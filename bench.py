@@ -406,6 +406,28 @@ def main():
                     "ms_per_step": round(vdt / vsteps * 1e3, 4), "steps": vsteps,
                     "bit_identical_to_headline": bool(same), "roofline": vroof,
                 }
+            # the persistent schedule: steps 1 .. K-1 of the whole batch in ONE launch of resident workgroups
+            # (csrc/mppersist.inc); wall-clock only -- its one launch has no per-step kernel to put on a roofline
+            nat.profile_enable(0)
+            pflags = nat.MP_FLAG_FFT_PERSISTENT
+            pout = nat.encode(x, du, K_ITERS, path=nat.MP_PATH_FFT, flags=pflags)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(args.steps):
+                pout = nat.encode(x, du, K_ITERS, path=nat.MP_PATH_FFT, flags=pflags)
+            torch.cuda.synchronize()
+            pdt = time.perf_counter() - t0
+            pst = nat.persist_stats()
+            line["variants"]["fft_persistent_one_launch"] = {
+                "value": round(B_PER_GPU * K_ITERS * args.steps / pdt, 2), "unit": "segment-iterations/s",
+                "ms_per_step": round(pdt / args.steps * 1e3, 4), "steps": args.steps,
+                "bit_identical_to_headline": bool(all(torch.equal(p, q) for p, q in zip(pout, out))),
+                "screen_task_us": round(pst["task_ticks"] / max(pst["tasks"], 1) / 100.0, 2),
+                "select_us": round(pst["select_ticks"] / max(pst["selects"], 1) / 100.0, 2),
+                "select_phase_us": pst["select_phase_us"], "error": pst["error"],
+                "note": "MP_FLAG_FFT_PERSISTENT: screen tasks of 8 atom pairs pulled from a queue by resident 256-thread "
+                        "workgroups, 64 select workers; hand-offs inside the launch (DESIGN.md 4c)",
+            }
             # the library default once more, replayed from a captured hipGraph (mpcore.EncodePlan)
             nat.profile_enable(0)  # (no timing events inside the captured graph)
             plan = nat.EncodePlan(B_PER_GPU, N, du, K_ITERS, path=nat.MP_PATH_FFT)
