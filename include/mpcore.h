@@ -101,8 +101,6 @@ int mp_profile_enable(int every);
 #define MP_TUNE_SCREEN_PPS 2
 #define MP_TUNE_GROUPS 3
 #define MP_TUNE_AUDIT 4
-#define MP_TUNE_PERSIST_STAGGER 7 /* MP_FLAG_FFT_PERSISTENT: 10-ns ticks between the releases of the batch's initial queue
-                                     entries (< 0 = heuristic: one 46 us cycle spread over the batch)                */
 #define MP_TUNE_PERSIST_SHARDS 6 /* MP_FLAG_FFT_PERSISTENT: number of ticket counters the screen workers are split over
                                     (0 = heuristic: one per ~512 workers)                                          */
 int mp_tune(int key, double value);

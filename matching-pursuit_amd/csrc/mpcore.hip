@@ -1741,7 +1741,6 @@ int mp_tune(int key, double value) {
     if (key == MP_TUNE_GROUPS && value >= 2 && value <= MAX_GROUPS) { overlap_groups.store((int)value); return MP_OK; }
     if (key == MP_TUNE_AUDIT) { audit_on.store((int)value); return MP_OK; }  // bit 0: screen audit; bit 1: persistent-schedule latencies
     if (key == MP_TUNE_PERSIST_SHARDS && value >= 0) { persist_shards.store((int)value); return MP_OK; }
-    if (key == MP_TUNE_PERSIST_STAGGER) { persist_stagger.store((int)value); return MP_OK; }
     return fail(MP_ERR_ARG, "mp_tune: unknown key or bad value%s");
 }
 
