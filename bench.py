@@ -10,13 +10,14 @@ rank per GPU) every rank encodes its own 64 segments (configs[2] at N = 8: 512 s
 collective on the data path, weak scaling; rank 0 prints ONE JSON line.
 
 value = segment-iterations/s over all ranks, inputs resident in HBM, timed between
-barrier+synchronize pairs, max over ranks, on the library's default kernels (MP_PATH_FFT: FFT
-screen + exact refinement; events bit-identical to the direct paths, re-checked every run) with the
-batch kept on ONE stream (MP_FLAG_NO_OVERLAP), so that the event-timed kernel durations are not
-stretched by a second sub-batch; `variants` carries the library's own default (four sub-batches on
-forked streams, a few percent faster), its replay from a captured hipGraph (mpcore.EncodePlan) and the two
-direct-correlation (MFMA) schedules with their own rooflines.  `roofline` is for the dominant kernel from HIP
-events recorded inside the timed region on the launch stream (sampled: every 16th iteration, see launch_times).
+barrier+synchronize pairs, max over ranks, on the library's default schedule for this shape (flags = 0:
+MP_PATH_FFT, FFT screen + exact refinement, events bit-identical to the direct paths, re-checked every run; from 48
+segments up the persistent form -- step 0 as separate kernels, steps 1 .. K-1 of the whole batch in ONE launch,
+csrc/mppersist.inc).  `variants` carries the launch-per-step forms of the same schedule (one stream: the form whose
+per-step screen kernel has its own roofline; four sub-batches on forked streams), the default's replay from a
+captured hipGraph (mpcore.EncodePlan) and the two direct-correlation (MFMA) schedules with their own rooflines.
+`roofline` is for the dominant kernel from HIP events recorded inside the timed region on the launch stream (the
+persistent launch: one span per encode; launch-per-step forms: sampled every 16th iteration, see launch_times).
 For the FFT schedule the bound is packed-fp32 VALU issue, NOT HBM: the screen's spectra are L2 / Infinity-Cache
 resident, and the measured fabric traffic (`traffic`, from the committed PMC passes) over the kernel time is
 reported beside it as `hbm_gbs_measured` / `frac_hbm`.  `cpu_baseline` is the CPU oracle timed on this host
@@ -211,6 +212,65 @@ def roofline_fft(prof, n_segments, steps):
     return out
 
 
+def roofline_persistent(prof, n_segments, steps):
+    """Roofline of fft_persistent_kernel (steps 1 .. K-1 of the whole batch in one launch) on packed-fp32 VALU issue.
+
+    achieved = the screens' ALGORITHMIC wave-instructions per launch (segments x A/2 pair transforms x (K-1) steps x
+    waves per transform x 410) / the launch's duration (one HIP-event span per encode).  The selects that run inside
+    the same launch (bound scan, exact fp32 chains of the contender quarter-cells, subtraction, next window's
+    transform) are NOT counted as algorithmic work, so the fraction is the share of the launch the chip spends
+    issuing screen arithmetic at peak; the step-0 screen (a separate launch) is reported beside it."""
+    ms_full, n_full = prof["corr_full"]
+    ms_p, n_p = prof["corr_inc"]
+    if n_p == 0:
+        return None
+    M, V = fft_geometry()
+    waves = M // 16 // 64
+    transforms = n_segments * (A // 2) * (K_ITERS - 1)
+    wave_instr = transforms * waves * VALU_PER_THREAD_TRANSFORM
+    avg_s = ms_p / n_p * 1e-3
+    achieved = wave_instr / avg_s / 1e9
+    traffic = pmc_traffic("fft_persistent")
+    t0 = n_segments * (A // 2) * -(-N // V)
+    out = {
+        "bound": "valu", "achieved": round(achieved, 1), "peak": round(PEAK_VALU_GINSTR, 1),
+        "unit": "G wave64-instructions/s (packed fp32 issue)",
+        "frac": round(achieved / PEAK_VALU_GINSTR, 4), "traffic": traffic,
+        "kernel": "fft_persistent_kernel<11,2> (queue of radix-16 Stockham screen tasks + select workers, one launch "
+                  "for steps 1 .. K-1)",
+        "launches": steps, "avg_launch_ms": round(avg_s * 1e3, 5),
+        "timed_with_events": {"persistent_launch": n_p, "step0_screen": n_full, "sampling": "every launch"},
+        "algorithmic_wave_instructions_per_launch": wave_instr, "transforms_per_launch": transforms,
+        "valu_floor_ms_per_launch": round(wave_instr / (PEAK_VALU_GINSTR * 1e9) * 1e3, 5),
+        "step0_screen_avg_ms": round(ms_full / max(n_full, 1), 5),
+        "step0_screen_frac_valu": round(t0 * waves * VALU_PER_THREAD_TRANSFORM / (ms_full / max(n_full, 1) * 1e-3) / 1e9
+                                        / PEAK_VALU_GINSTR, 4) if n_full else None,
+        "other_kernels_avg_ms_per_encode": round(prof["select"][0] / max(n_p, 1), 5),
+    }
+    if traffic is not None:
+        out["hbm_gbs_measured"] = round(traffic / avg_s / 1e9, 1)
+        out["frac_hbm"] = round(traffic / avg_s / 1e9 / PEAK_HBM_GBS, 4)
+    pst = nat.persist_stats()
+    out["inside_the_launch"] = {
+        "screen_task_us": round(pst["task_ticks"] / max(pst["tasks"], 1) / 100.0, 2), "tasks": pst["tasks"],
+        "select_us": round(pst["select_ticks"] / max(pst["selects"], 1) / 100.0, 2), "selects": pst["selects"],
+        "select_phase_us": pst["select_phase_us"], "error": pst["error"],
+    }
+    out["note"] = ("HBM does not bind this kernel and the north-star's >= 70 % HBM target does not apply to it: the spectra "
+                   "the screen tasks stream are L2 / Infinity-Cache hits (4 MiB of pair spectra shared by all segments); "
+                   "fabric traffic is `traffic` bytes per launch (FETCH_SIZE x 2 + WRITE_SIZE, separate rocprofv3 --pmc "
+                   "passes, profiles/).  The same screen arithmetic launched per step (variants."
+                   "fft_launch_per_step_one_stream.roofline) is the per-kernel figure: there the kernel is ONLY the "
+                   "screen; here the launch also holds every select of every step and the hand-offs between them "
+                   "(DESIGN.md 4c).")
+    return out
+
+
+def ran_persistent(prof, steps):
+    """True if the encodes just timed took the persistent form (mp_last_schedule)."""
+    return nat.last_schedule() == -1
+
+
 def roofline_from(prof, flops_one_encode, steps):
     lt = launch_times(prof, steps)
     if lt is None:
@@ -316,11 +376,11 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--path", default="fft", choices=list(PATHS))
-    ap.add_argument("--flags", type=int, default=nat.MP_FLAG_NO_OVERLAP,
-                    help="MP_FLAG_* bits for the timed region.  Default: the single-stream schedule, so that the "
-                         "event-timed kernel durations the roofline is built on are not stretched by a second "
-                         "sub-batch running beside them; the library's own default for MP_PATH_FFT (four "
-                         "sub-batches on forked streams) is reported under variants.")
+    ap.add_argument("--flags", type=int, default=0,
+                    help="MP_FLAG_* bits for the timed region.  Default 0: whatever the library picks for the shape "
+                         "(MP_PATH_FFT at 64 segments: the persistent form); the launch-per-step forms "
+                         "(MP_FLAG_NO_OVERLAP = 4096: one stream; MP_FLAG_FFT_NO_PERSISTENT = 131072: sub-batches) are "
+                         "reported under variants.")
     ap.add_argument("--no-variants", action="store_true", help="skip the direct-path variant leg")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--backend", default=None, help="torch.distributed backend (default nccl = RCCL)")
@@ -361,7 +421,7 @@ def main():
     atom, lag, gain, residual = [t.cpu().numpy() for t in out]
     seg_its = world * B_PER_GPU * K_ITERS * args.steps
     if path == nat.MP_PATH_FFT:
-        roof = roofline_fft(prof, B_PER_GPU, args.steps)
+        roof = (roofline_persistent if ran_persistent(prof, args.steps) else roofline_fft)(prof, B_PER_GPU, args.steps)
     else:
         roof = roofline_from(prof, algorithmic_flops(lag, path), args.steps)
     rdb = 20 * np.log10(np.linalg.norm(residual, axis=-1) / np.linalg.norm(x_host, axis=-1))
@@ -387,10 +447,11 @@ def main():
     if rank == 0 and world == 1:
         if not args.no_variants:
             line["variants"] = {}
-            for name, other, vflags in (("fft_sub_batches_library_default", nat.MP_PATH_FFT, 0),
-                                        ("incremental_direct_mfma", nat.MP_PATH_INCREMENTAL, args.flags),
-                                        ("direct_full_recompute_mfma", nat.MP_PATH_DIRECT, args.flags),
-                                        ("fft_screen_refine", nat.MP_PATH_FFT, args.flags)):
+            for name, other, vflags in (("fft_launch_per_step_one_stream", nat.MP_PATH_FFT, nat.MP_FLAG_NO_OVERLAP),
+                                        ("fft_launch_per_step_sub_batches", nat.MP_PATH_FFT, nat.MP_FLAG_FFT_NO_PERSISTENT),
+                                        ("fft_library_default", nat.MP_PATH_FFT, 0),
+                                        ("incremental_direct_mfma", nat.MP_PATH_INCREMENTAL, nat.MP_FLAG_NO_OVERLAP),
+                                        ("direct_full_recompute_mfma", nat.MP_PATH_DIRECT, nat.MP_FLAG_NO_OVERLAP)):
                 if other == path and vflags == args.flags:
                     continue
                 vsteps = 1 if other == nat.MP_PATH_DIRECT else max(1, min(args.steps, 3))
@@ -399,35 +460,15 @@ def main():
                 vdt, vout, vprof = timed_encodes(x, du, vsteps, 1, other, vflags, group)
                 vlag = vout[1].cpu().numpy()
                 same = all(torch.equal(p, q) for p, q in zip(vout, out))
-                vroof = (roofline_fft(vprof, B_PER_GPU, vsteps) if other == nat.MP_PATH_FFT
-                         else roofline_from(vprof, algorithmic_flops(vlag, other), vsteps))
+                if other == nat.MP_PATH_FFT:
+                    vroof = (roofline_persistent if ran_persistent(vprof, vsteps) else roofline_fft)(vprof, B_PER_GPU, vsteps)
+                else:
+                    vroof = roofline_from(vprof, algorithmic_flops(vlag, other), vsteps)
                 line["variants"][name] = {
                     "value": round(B_PER_GPU * K_ITERS * vsteps / vdt, 2), "unit": "segment-iterations/s",
                     "ms_per_step": round(vdt / vsteps * 1e3, 4), "steps": vsteps,
                     "bit_identical_to_headline": bool(same), "roofline": vroof,
                 }
-            # the persistent schedule: steps 1 .. K-1 of the whole batch in ONE launch of resident workgroups
-            # (csrc/mppersist.inc); wall-clock only -- its one launch has no per-step kernel to put on a roofline
-            nat.profile_enable(0)
-            pflags = nat.MP_FLAG_FFT_PERSISTENT
-            pout = nat.encode(x, du, K_ITERS, path=nat.MP_PATH_FFT, flags=pflags)
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            for _ in range(args.steps):
-                pout = nat.encode(x, du, K_ITERS, path=nat.MP_PATH_FFT, flags=pflags)
-            torch.cuda.synchronize()
-            pdt = time.perf_counter() - t0
-            pst = nat.persist_stats()
-            line["variants"]["fft_persistent_one_launch"] = {
-                "value": round(B_PER_GPU * K_ITERS * args.steps / pdt, 2), "unit": "segment-iterations/s",
-                "ms_per_step": round(pdt / args.steps * 1e3, 4), "steps": args.steps,
-                "bit_identical_to_headline": bool(all(torch.equal(p, q) for p, q in zip(pout, out))),
-                "screen_task_us": round(pst["task_ticks"] / max(pst["tasks"], 1) / 100.0, 2),
-                "select_us": round(pst["select_ticks"] / max(pst["selects"], 1) / 100.0, 2),
-                "select_phase_us": pst["select_phase_us"], "error": pst["error"],
-                "note": "MP_FLAG_FFT_PERSISTENT: screen tasks of 8 atom pairs pulled from a queue by resident 256-thread "
-                        "workgroups, 64 select workers; hand-offs inside the launch (DESIGN.md 4c)",
-            }
             # the library default once more, replayed from a captured hipGraph (mpcore.EncodePlan)
             nat.profile_enable(0)  # (no timing events inside the captured graph)
             plan = nat.EncodePlan(B_PER_GPU, N, du, K_ITERS, path=nat.MP_PATH_FFT)

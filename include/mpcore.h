@@ -68,8 +68,11 @@ extern "C" {
                                        of the one-kernel quarter-cell select (default when the batch is split)    */
 #define MP_FLAG_FFT_QUARTER 16384   /* MP_PATH_FFT: the quarter-cell select also when the batch stays on one stream */
 #define MP_FLAG_FFT_PERSISTENT 65536 /* MP_PATH_FFT: steps 1 .. K-1 of the whole batch in ONE launch of resident workgroups that
-                                        pull screen tasks and run a segment's select when its last task completes
-                                        (csrc/mppersist.inc); shapes it does not cover fall back to the other forms  */
+                                        pull screen tasks from a queue while select workers serve the segments whose screens
+                                        are complete (csrc/mppersist.inc).  Default from 48 segments up where it applies
+                                        (no split transforms, <= 16384 cells per segment, 1024 <= M <= 4096); this flag
+                                        asks for it at any batch size; shapes it does not cover use the other forms   */
+#define MP_FLAG_FFT_NO_PERSISTENT 131072 /* MP_PATH_FFT: launch-per-step kernels (sub-batches on forked streams from 48 segments) */
 #define MP_FLAG_GROUPS_SHIFT 20
 #define MP_FLAG_GROUPS(n) (((n) & 7) << MP_FLAG_GROUPS_SHIFT) /* this call: n (2..4) sub-batches where the batch is split */
 #define MP_FLAG_NO_PERSISTENT 8 /* one workgroup per 4 cells instead of machine-sized persistent grid */
@@ -192,6 +195,11 @@ float mp_stream_pair_ratio(int q0, int q1);
  * encode into a hipGraph if the graph should contain sub-batches.  Returns the number of internal streams seen
  * to run side by side (>= 1; sub-batches need >= 2), or a negative error (e.g. `stream` is being captured). */
 int mp_init_streams(void *stream);
+
+/* Which form the calling thread's last mp_encode_f32 / mp_encode_conv_f32 took: -1 = the persistent form (step 0, then
+ * one launch for steps 1 .. K-1), 1 = one kernel sequence per step on the caller's stream, n >= 2 = n sub-batches on
+ * forked internal streams; 0 before the first encode.  No device work. */
+int mp_last_schedule(void);
 
 /* Debug: statistics of the last MP_FLAG_FFT_PERSISTENT launch on the current device, summed over its workgroups --
  * out16[0..2] = 100 MHz wall-clock ticks spent idle (polling the queue), in screen tasks, in selects; [3..5] = tasks,

@@ -1079,6 +1079,7 @@ __global__ __launch_bounds__(1024) void dictionary_update_level_kernel(
 #include "mpfft.inc"
 
 constexpr int MP_FLAG_FFT_PERSISTENT_BIT = 65536;  // (= MP_FLAG_FFT_PERSISTENT, include/mpcore.h)
+thread_local int last_schedule = 0;  // mp_last_schedule(): -1 persistent, 1 one stream, n >= 2 sub-batches
 
 struct Workspace {
     float *res;
@@ -1383,6 +1384,21 @@ TauModel fft_tau(int logM) {
     return TauModel{5.9604645e-8f, 1.001f, FFT_TAU_C * (float)logM};
 }
 
+// Zero `bytes` (a multiple of 4, 4-byte aligned) on the stream, as a kernel: a captured encode then holds kernel nodes
+// only (a replayed hipGraph whose persistent launch depends on the cleared queue must not depend on how the runtime
+// orders its memset nodes -- seen: correct on the first replay, into fresh zero pages, stale state on the second).
+__global__ void clear_words_kernel(unsigned *__restrict__ p, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) p[i] = 0u;
+}
+int clear_async(void *p, size_t bytes, hipStream_t st) {
+    const size_t n = bytes / 4;
+    if (!n) return MP_OK;
+    const size_t blocks = std::min<size_t>((n + 255) / 256, 4096);
+    hipLaunchKernelGGL(clear_words_kernel, dim3((unsigned)blocks), dim3(256), 0, st, static_cast<unsigned *>(p), n);
+    HIP_TRY(hipGetLastError());
+    return MP_OK;
+}
+
 // once per encode, whole batch, on the caller's stream: twiddles, pair spectra, cleared keys / flags
 int fft_setup(const Geom &g, const Workspace &w, const float *du, int flags, hipStream_t st) {
     FftGeom f;
@@ -1393,10 +1409,10 @@ int fft_setup(const Geom &g, const Workspace &w, const float *du, int flags, hip
     const int64_t n_cells = (int64_t)g.NBLK * g.NAT;
     const int npairs = g.NAT * f.NPT;
     int rc;
-    HIP_TRY(hipMemsetAsync(w.overflow, 0, (size_t)g.B * sizeof(int), st));
-    HIP_TRY(hipMemsetAsync(w.ekeys, 0, (size_t)g.B * (MAXCONT + 1) * sizeof(u64), st));
-    HIP_TRY(hipMemsetAsync(w.bsum, 0, (size_t)g.B * g.NBLK * 2 * sizeof(unsigned), st));
-    HIP_TRY(hipMemsetAsync(w.keys, 0, (size_t)g.B * n_cells * sizeof(u64), st));
+    if ((rc = clear_async(w.overflow, (size_t)g.B * sizeof(int), st))) return rc;
+    if ((rc = clear_async(w.ekeys, (size_t)g.B * (MAXCONT + 1) * sizeof(u64), st))) return rc;
+    if ((rc = clear_async(w.bsum, (size_t)g.B * g.NBLK * 2 * sizeof(unsigned), st))) return rc;
+    if ((rc = clear_async(w.keys, (size_t)g.B * n_cells * sizeof(u64), st))) return rc;
     if (f.split) {  // long atoms: two half-size transforms per M-point transform (mpfft.inc)
         constexpr int LH = SPLIT_LOGH;
         const int H = f.M / 2;
@@ -1812,7 +1828,7 @@ static int encode_impl(const float *signal, int64_t B, int64_t N, const float *d
         FftGeom f;
         if (!make_fft_geom(g, &f)) return fail(MP_ERR_UNSUPPORTED, "MP_PATH_FFT: atom too long%s");
         const TauModel tm = fft_tau(f.logM);
-        HIP_TRY(hipMemsetAsync(w.dscale, 0, sizeof(float), st));
+        if ((rc = clear_async(w.dscale, sizeof(float), st))) return rc;
         hipLaunchKernelGGL(max_row_norm_kernel, dim3((unsigned)((A + 3) / 4)), dim3(256), 0, st, dict_unit, A, L, w.dscale,
                            tm.chain_w, tm.fft_w);
         HIP_TRY(hipGetLastError());
@@ -1829,11 +1845,21 @@ static int encode_impl(const float *signal, int64_t B, int64_t N, const float *d
     // opt-in elsewhere (MP_FLAG_OVERLAP).  Only on streams seen to run side by side (stream_pool).
     // The persistent schedule (mppersist.inc): step 0 as separate kernels (full-pass screen, quarter select), then
     // steps 1 .. K-1 of the whole batch in one launch of resident workgroups.
-    if (path == MP_PATH_FFT && (flags & MP_FLAG_FFT_PERSISTENT_BIT)) {
+    // Default for MP_PATH_FFT from 48 segments up where it applies (MP_FLAG_FFT_NO_PERSISTENT, or any flag that asks for
+    // a particular launch-per-step form or sub-batch count, turns it off; MP_FLAG_FFT_PERSISTENT asks for it at any size).
+    // Measured at the headline shape, ten encodes back to back (bench.py): 899 k segment-iterations/s against 805 k on
+    // four sub-batches and 768 k on one stream; level with the sub-batches when every encode is synchronised.
+    const int forms = MP_FLAG_NO_OVERLAP | MP_FLAG_OVERLAP | MP_FLAG_FFT_NO_QUARTER | MP_FLAG_FFT_QUARTER | MP_FLAG_FFT_FUSED |
+                      MP_FLAG_FFT_UNFUSED | MP_FLAG_REFINE_MFMA | MP_FLAG_FFT_SIMPLE | MP_FLAG_FFT_NO_PERSISTENT |
+                      (7 << MP_FLAG_GROUPS_SHIFT);
+    const bool persist = path == MP_PATH_FFT && ((flags & MP_FLAG_FFT_PERSISTENT_BIT) || (B >= 48 && !(flags & forms))) &&
+                         !audit_on.load(std::memory_order_relaxed);  // (the audit checks screens launch by launch)
+    if (persist) {
         FftGeom f;
         if (make_fft_geom(g, &f) && persist_eligible(g, f, w, K)) {
             const int f0 = (flags & ~(MP_FLAG_FFT_NO_QUARTER | MP_FLAG_FFT_FUSED | MP_FLAG_FFT_UNFUSED | MP_FLAG_REFINE_MFMA |
-                                      MP_FLAG_FFT_SIMPLE)) | MP_FLAG_FFT_QUARTER | MP_FLAG_INTERNAL_ONE_STREAM;
+                                      MP_FLAG_FFT_SIMPLE)) | MP_FLAG_FFT_QUARTER | MP_FLAG_INTERNAL_ONE_STREAM | MP_FLAG_FFT_PERSISTENT_BIT;
+            last_schedule = -1;
             g_prof.arm(0);
             if ((rc = fft_iteration(g, w, dict_unit, K, 0, f0, out_atom, out_lag, out_gain, rule, st))) return rc;
             g_prof.begin(PROF_CORR_INC, st);  // (one span around the whole launch: steps 1 .. K-1)
@@ -1865,6 +1891,7 @@ static int encode_impl(const float *signal, int64_t B, int64_t N, const float *d
         if (pool && n_groups > pool->n_concurrent) n_groups = pool->n_concurrent;  // never sub-batches on one hardware queue
         if (!pool || n_groups < 2) { n_groups = 1; pool = nullptr; }
     }
+    last_schedule = n_groups;
     if (pool) {
         HIP_TRY(hipEventRecord(pool->fork, st));
         for (int q = 0; q < n_groups; ++q) HIP_TRY(hipStreamWaitEvent(pool->streams[q], pool->fork, 0));
@@ -2230,6 +2257,8 @@ int mp_persist_stats(uint64_t *out8 /* [16] */) {
     }
     return MP_OK;
 }
+
+int mp_last_schedule(void) { return last_schedule; }
 
 int mp_init_streams(void *stream) {
     StreamPool *p = stream_pool(static_cast<hipStream_t>(stream));

@@ -36,6 +36,7 @@ MP_FLAG_FFT_UNFUSED = 512
 MP_FLAG_FFT_FUSED = 1024
 MP_FLAG_OVERLAP = 2048
 MP_FLAG_FFT_PERSISTENT = 65536
+MP_FLAG_FFT_NO_PERSISTENT = 131072
 
 EXPORTS = (
     "mp_version", "mp_last_error", "mp_workspace_bytes", "mp_unit_norm_f32", "mp_encode_f32",
@@ -43,7 +44,7 @@ EXPORTS = (
     "mp_profile_enable", "mp_profile_read", "mp_fft_c2c_f32", "mp_encode_conv_f32", "mp_tune",
     "mp_dictionary_update_f32", "mp_lcn_workspace_bytes", "mp_encode_lcn_f32", "mp_conv_model_backward_f32",
     "mp_stream_pair_ratio", "mp_init_streams", "mp_audit_read", "mp_dictionary_levels_host",
-    "mp_dictionary_update_levels_f32", "mp_persist_stats",
+    "mp_dictionary_update_levels_f32", "mp_persist_stats", "mp_last_schedule",
 )
 
 
@@ -141,6 +142,11 @@ def init_streams(device=None):
     if n < 0:
         raise NativeError(f"mp_init_streams failed (rc={n}): {lib().mp_last_error().decode()}")
     return int(n)
+
+
+def last_schedule():
+    """mp_last_schedule: -1 persistent form, 1 one stream, n >= 2 sub-batches (this thread's last encode)."""
+    return int(lib().mp_last_schedule())
 
 
 def persist_stats():
@@ -296,7 +302,8 @@ class EncodePlan:
     scripts/graph_groups.py): 1.15x at BASELINE configs[0] (one segment, 8 steps: 226 -> 198 us); at the headline
     shape a replay (848 k segment-iterations/s) beats the one-stream schedule (819 k) but not the plain launches of
     the four-sub-batch default (877 k): a graph's parallel branches run on the runtime's own streams, which share
-    hardware queues beyond two -- so a plan is captured with two sub-batches.
+    hardware queues beyond two -- so a plan is captured with two sub-batches unless the shape takes the persistent
+    form (one launch for steps 1 .. K-1: no branches), which is captured as it is.
 
         plan = EncodePlan(B, N, dict_unit, n_steps)        # captures; the dictionary is read at replay time
         atom, lag, gain, residual = plan(signal)             # [B, N] -> views of the plan's static outputs
@@ -304,16 +311,21 @@ class EncodePlan:
     The outputs are overwritten by the next call (clone what must outlive it).  As with encode(), a segment
     whose FFT screen overflowed is marked with gain = NaN: encode_checked() is the checked, un-captured form."""
 
-    def __init__(self, batch, n_samples, dict_unit, n_steps, path=None, flags=0, want_residual=True, sub_batches=2):
+    def __init__(self, batch, n_samples, dict_unit, n_steps, path=None, flags=0, want_residual=True, sub_batches=None):
         dict_unit = _f32(dict_unit)
         _require_cuda(dict_unit)
         self.path = default_path(dict_unit.shape[1]) if path is None else path
         self.dict_unit = dict_unit
         dev = dict_unit.device
         self.signal = torch.zeros((int(batch), int(n_samples)), dtype=torch.float32, device=dev)
-        # the sub-batch count is a per-call flag: nothing process-wide is touched while other threads encode
-        args = dict(path=self.path, flags=int(flags) | flag_groups(max(2, min(4, int(sub_batches)))),
-                    want_residual=want_residual)
+        # sub_batches=None: the library's choice for the shape (the persistent form where it applies, else two
+        # sub-batches); a number: that many.  A per-call flag: nothing process-wide is touched while other threads encode
+        if sub_batches is None:
+            encode(self.signal, dict_unit, n_steps, path=self.path, flags=int(flags), want_residual=False)
+            groups = 0 if last_schedule() == -1 else 2
+        else:
+            groups = max(2, min(4, int(sub_batches)))
+        args = dict(path=self.path, flags=int(flags) | (flag_groups(groups) if groups else 0), want_residual=want_residual)
         with torch.cuda.device(dev):
             init_streams(dev)  # the pool's self-test synchronises with the host: before the capture, not inside it
         self._capture(dev, n_steps, args)

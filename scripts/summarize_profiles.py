@@ -19,7 +19,7 @@ def newest(pattern):
 
 
 def short(name):
-    for key in ("correlate_persistent_kernel", "correlate_mfma_kernel", "correlate_naive_kernel",
+    for key in ("fft_persistent_kernel", "persist_init_kernel", "persist_error_kernel", "correlate_persistent_kernel", "correlate_mfma_kernel", "correlate_naive_kernel",
                 "fft_screen_kernel", "fft_correlate_kernel", "fft_refine_valu_kernel",
                 "fft_refine_kernel", "fft_scan_refine_kernel", "fft_select_a_kernel", "fft_select_b_kernel", "fft_select_fused_kernel", "fft_select_quarter_kernel", "fft_window_kernel",
                 "fft_dict_kernel", "fft_twiddle_kernel", "fft_mark_overflow_kernel",
@@ -66,10 +66,12 @@ if fs:
     seen = set()
     for which, path in enumerate(fs + fs2):
         for r in csv.DictReader(open(path)):
-            if "correlate" not in r["Kernel_Name"] and "fft_screen" not in r["Kernel_Name"]:
+            if not any(k in r["Kernel_Name"] for k in ("correlate", "fft_screen", "fft_persistent")):
                 continue
             d = int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
             kind = "full_pass" if d > (5e5 if "fft_screen" in r["Kernel_Name"] else 3e6) else "incremental"
+            if "fft_persistent" in r["Kernel_Name"]:
+                kind = "persistent_launch"
             agg[kind][r["Counter_Name"]] += float(r["Counter_Value"])
             if which == 0 and r["Dispatch_Id"] not in seen:
                 seen.add(r["Dispatch_Id"])
@@ -99,7 +101,7 @@ if fs:
 fk = summary.get("FETCH_SIZE_KB", {})
 wk = summary.get("WRITE_SIZE_KB", {})
 for k in fk:
-    if ("correlate" in k or "fft_screen" in k) and k in wk:
+    if ("correlate" in k or "fft_screen" in k or "fft_persistent" in k) and k in wk:
         summary["hbm_traffic_bytes_per_launch_" + k.split("<")[0]] = int(
             (2 * fk[k]["avg_per_launch"] + wk[k]["avg_per_launch"]) * 1024)
 json.dump(summary, open(dst + "_summary.json", "w"), indent=1)

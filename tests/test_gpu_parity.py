@@ -671,11 +671,60 @@ def test_init_streams_and_capture_in_a_thread_without_a_pool(oracle):
     assert np.array_equal(out[0][2], want["gain"]) and np.array_equal(out[0][3], want["residual"])
 
 
+def test_which_form_the_default_schedule_takes():
+    """flags = 0 on MP_PATH_FFT: the persistent form from 48 segments up where the shape allows it (here 1024-point
+    transforms), sub-batches on forked streams where it does not (512-point transforms) or when a flag names another
+    form, one stream below 48 segments; mp_last_schedule() tells which.  All bit-identical."""
+    d = synth.make_dictionary(64, 256, seed=61)
+    du = nat.unit_norm(torch.from_numpy(d).to(DEV))
+    x = torch.from_numpy(synth.make_segments(56, 6000, d, n_events=10, seed=62)).to(DEV)
+    streams = min(4, nat.init_streams())
+    ref = nat.encode(x, du, 7, path=nat.MP_PATH_FFT, flags=nat.MP_FLAG_NO_OVERLAP)
+    assert nat.last_schedule() == 1
+    for flags, n, want in ((0, 56, -1), (0, 47, 1), (nat.MP_FLAG_FFT_PERSISTENT, 5, -1), (nat.MP_FLAG_FFT_NO_PERSISTENT, 56, streams),
+                           (nat.flag_groups(2), 56, min(2, streams)), (nat.MP_FLAG_FFT_FUSED, 56, streams)):
+        out = nat.encode(x[:n], du, 7, path=nat.MP_PATH_FFT, flags=flags)
+        assert nat.last_schedule() == want, (flags, n, nat.last_schedule())
+        assert all(torch.equal(p, q[:n]) for p, q in zip(out, ref)), (flags, n)
+    nat.encode(x, du, 1, path=nat.MP_PATH_FFT)        # a single step has no steps 1 .. K-1 to put in one launch
+    assert nat.last_schedule() == streams
+    d2 = synth.make_dictionary(40, 96, seed=51)       # 512-point transforms: outside the persistent form
+    x2 = torch.from_numpy(synth.make_segments(50, 3000, d2, n_events=10, seed=52)).to(DEV)
+    nat.encode(x2, nat.unit_norm(torch.from_numpy(d2).to(DEV)), 4, path=nat.MP_PATH_FFT)
+    assert nat.last_schedule() == streams
+    nat.encode(x, du, 7, path=nat.MP_PATH_INCREMENTAL)
+    assert nat.last_schedule() == 1
+
+
+def test_persistent_form_replayed_from_a_graph(oracle):
+    """The persistent form captured into a hipGraph and replayed: every replay bit-identical to the oracle.  The
+    launch depends on its queue having been cleared by THIS replay (the first replay runs into fresh zero pages, so
+    only later ones tell): the library clears with kernels, not memset nodes, for that reason."""
+    d = synth.make_dictionary(64, 256, seed=61)
+    du_np = oracle.unit_norm(d)
+    du = torch.from_numpy(du_np).to(DEV)
+    x_host = synth.make_segments(50, 6000, d, n_events=10, seed=62)
+    want = oracle.encode(x_host, du_np, 9)
+    plan = nat.EncodePlan(50, 6000, du, 9, path=nat.MP_PATH_FFT)
+    assert nat.last_schedule() == -1
+    x = torch.from_numpy(x_host).to(DEV)
+    for rep in range(4):
+        a, l, g, r = plan(x if rep != 2 else torch.zeros_like(x))   # (replay 2 on other data: stale state would differ)
+        torch.cuda.synchronize()
+        if rep == 2:
+            assert (g == 0).all() and (r == 0).all()
+            continue
+        assert np.array_equal(a.cpu().numpy(), want["atom"]) and np.array_equal(l.cpu().numpy(), want["lag"]), rep
+        assert np.array_equal(g.cpu().numpy(), want["gain"]) and np.array_equal(r.cpu().numpy(), want["residual"]), rep
+    assert nat.persist_stats()["error"] == 0
+
+
 # ---- BASELINE.json configs at FULL size --------------------------------------------------------------------------
 def test_config1_full_size_default_schedule(oracle):
-    """configs[1]: 512 x 512 dictionary, B = 64 segments of 32768 samples, K = 64 on the library default (four
-    sub-batches on forked streams).  Size-independent properties over the whole job, the oracle on a 4-segment x
-    16-step sample, and the one-stream and incremental schedules bit for bit."""
+    """configs[1]: 512 x 512 dictionary, B = 64 segments of 32768 samples, K = 64 on the library default (at this
+    shape the persistent form: step 0, then one launch for steps 1 .. 63).  Size-independent properties over the
+    whole job, the oracle on a 4-segment x 16-step sample, and the launch-per-step forms (one stream, four
+    sub-batches on forked streams) and the incremental schedule bit for bit."""
     A, L, N, B, K = 512, 512, 32768, 64, 64
     d = synth.make_dictionary(A, L, seed=1000)
     x_host = synth.make_segments(B, N, d, n_events=3 * K, seed=1002)
@@ -683,6 +732,7 @@ def test_config1_full_size_default_schedule(oracle):
     du = nat.unit_norm(torch.from_numpy(d).to(DEV))
     atom, lag, gain, residual = nat.encode(x, du, K, path=nat.MP_PATH_FFT)
     torch.cuda.synchronize()
+    assert nat.last_schedule() == -1 and nat.persist_stats()["error"] == 0
     assert not torch.isnan(gain).any()                       # no screen overflow anywhere in the job
     assert (atom >= 0).all() and (atom < A).all() and (lag >= 0).all() and (lag < N).all()
     recon = torch.zeros_like(x)
@@ -693,7 +743,11 @@ def test_config1_full_size_default_schedule(oracle):
     assert (e1 < e0).all() and ((e0 - e1) >= 0.99 * ((gain.double() ** 2) * interior).sum(-1)).all()
     # per-step energy is non-increasing along every segment: replay the events step by step on a sample
     one = nat.encode(x, du, K, path=nat.MP_PATH_FFT, flags=nat.MP_FLAG_NO_OVERLAP)
+    assert nat.last_schedule() == 1
     assert all(torch.equal(p, q) for p, q in zip(one, (atom, lag, gain, residual)))
+    sub = nat.encode(x, du, K, path=nat.MP_PATH_FFT, flags=nat.MP_FLAG_FFT_NO_PERSISTENT)
+    assert nat.last_schedule() == min(4, nat.init_streams())
+    assert all(torch.equal(p, q) for p, q in zip(sub, (atom, lag, gain, residual)))
     inc = nat.encode(x[:8], du, K, path=nat.MP_PATH_INCREMENTAL)
     assert torch.equal(inc[0], atom[:8]) and torch.equal(inc[1], lag[:8]) and torch.equal(inc[2], gain[:8])
     assert torch.equal(inc[3], residual[:8])
