@@ -69,7 +69,7 @@ extern "C" {
 #define MP_FLAG_FFT_QUARTER 16384   /* MP_PATH_FFT: the quarter-cell select also when the batch stays on one stream */
 #define MP_FLAG_FFT_PERSISTENT 65536 /* MP_PATH_FFT: steps 1 .. K-1 of the whole batch in ONE launch of resident workgroups that
                                         pull screen tasks from a queue while select workers serve the segments whose screens
-                                        are complete (csrc/mppersist.inc).  Default from 40 segments up where it applies
+                                        are complete (csrc/mppersist.inc).  Default from 24 segments up where it applies
                                         (no split transforms, <= 16384 cells per segment, 1024 <= M <= 4096); this flag
                                         asks for it at any batch size; shapes it does not cover use the other forms   */
 #define MP_FLAG_FFT_NO_PERSISTENT 131072 /* MP_PATH_FFT: launch-per-step kernels (sub-batches on forked streams from 48 segments) */
@@ -109,6 +109,8 @@ int mp_profile_enable(int every);
 #define MP_TUNE_PERSIST_WORKERS 7 /* persistent form: workgroups of the launch (0 = heuristic: 2, 3 or 4 per CU by the
                                      number of screen tasks the batch can have in flight)                          */
 #define MP_TUNE_PERSIST_SELECTS 8 /* persistent form: how many of them are select workers (0 = min(segments, 64))    */
+#define MP_TUNE_PERSIST_VARIANT 9 /* persistent form: 3 / 4 = the kernel compiled for three (168 VGPRs, pair spectra requested
+                                     one transform ahead) / four wavefronts per SIMD; 0 = three when the grid allows  */
 int mp_tune(int key, double value);
 int mp_profile_read(double *ms, int64_t *count);
 

@@ -1759,6 +1759,7 @@ int mp_tune(int key, double value) {
     if (key == MP_TUNE_PERSIST_SHARDS && value >= 0) { persist_shards.store((int)value); return MP_OK; }
     if (key == MP_TUNE_PERSIST_WORKERS && value >= 0) { persist_workers.store((int)value); return MP_OK; }
     if (key == MP_TUNE_PERSIST_SELECTS && value >= 0) { persist_selects.store((int)value); return MP_OK; }
+    if (key == MP_TUNE_PERSIST_VARIANT && (value == 0 || value == 3 || value == 4)) { persist_variant.store((int)value); return MP_OK; }
     return fail(MP_ERR_ARG, "mp_tune: unknown key or bad value%s");
 }
 
@@ -1847,16 +1848,15 @@ static int encode_impl(const float *signal, int64_t B, int64_t N, const float *d
     // opt-in elsewhere (MP_FLAG_OVERLAP).  Only on streams seen to run side by side (stream_pool).
     // The persistent schedule (mppersist.inc): step 0 as separate kernels (full-pass screen, quarter select), then
     // steps 1 .. K-1 of the whole batch in one launch of resident workgroups.
-    // Default for MP_PATH_FFT from 40 segments up where it applies (MP_FLAG_FFT_NO_PERSISTENT, or any flag that asks for
+    // Default for MP_PATH_FFT from 24 segments up where it applies (MP_FLAG_FFT_NO_PERSISTENT, or any flag that asks for
     // a particular launch-per-step form or sub-batch count, turns it off; MP_FLAG_FFT_PERSISTENT asks for it at any size).
     // Measured, headline dictionary, eight encodes back to back (scripts/persist_percu.py; k segment-iterations/s,
-    // persistent / one stream / sub-batches): 32 segments 656 / 644 / 649, 40: 777 / 661 / 663, 48: 845 / 726 / 750,
-    // 64: 1026 / 823 / 875, 96: 1112 / 837 / 987, 128: 1099 / 902 / 1053; the same picture with 1024- and 4096-point
-    // transforms (cross-over at 48 and 24 segments).
+    // persistent / one stream / sub-batches): 16 segments 415 / 420 / 388, 24: 577 / 519 / 520, 32: 732 / 572 / 647,
+    // 48: 930 / 726 / 703, 64: 1097 / 827 / 874, 96: 1118 / 835 / 987, 128: 1124 / 897 / 1056.
     const int forms = MP_FLAG_NO_OVERLAP | MP_FLAG_OVERLAP | MP_FLAG_FFT_NO_QUARTER | MP_FLAG_FFT_QUARTER | MP_FLAG_FFT_FUSED |
                       MP_FLAG_FFT_UNFUSED | MP_FLAG_REFINE_MFMA | MP_FLAG_FFT_SIMPLE | MP_FLAG_FFT_NO_PERSISTENT |
                       (7 << MP_FLAG_GROUPS_SHIFT);
-    const bool persist = path == MP_PATH_FFT && ((flags & MP_FLAG_FFT_PERSISTENT_BIT) || (B >= 40 && !(flags & forms))) &&
+    const bool persist = path == MP_PATH_FFT && ((flags & MP_FLAG_FFT_PERSISTENT_BIT) || (B >= 24 && !(flags & forms))) &&
                          !audit_on.load(std::memory_order_relaxed);  // (the audit checks screens launch by launch)
     if (persist) {
         FftGeom f;

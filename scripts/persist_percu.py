@@ -31,7 +31,7 @@ if mode == "percu":     # workgroups per CU against the batch size, and the laun
         row.append(f"heuristic {rate(B, x, nat.MP_FLAG_FFT_PERSISTENT):6.0f} k")
         row.append(f"per step, one stream {rate(B, x, nat.MP_FLAG_NO_OVERLAP):6.0f} k, sub-batches {rate(B, x, nat.MP_FLAG_FFT_NO_PERSISTENT):6.0f} k")
         print(f"B{B:4d}: " + " | ".join(row), flush=True)
-else:                   # one batch size: total workgroups x select workers
+elif mode != "variant": # one batch size: total workgroups x select workers
     B = int(mode)
     x = torch.from_numpy(synth.make_segments(B, N, d, n_events=192, seed=1002)).cuda()
     for nsel in (32, 48, 64):
@@ -41,3 +41,15 @@ else:                   # one batch size: total workgroups x select workers
             nat.tune(nat.MP_TUNE_PERSIST_WORKERS, workers)
             row.append(f"{workers}: {rate(B, x, nat.MP_FLAG_FFT_PERSISTENT):6.0f} k")
         print(f"B{B} select workers {nsel}: " + " | ".join(row), flush=True)
+if mode == "variant":   # the 3-wavefront kernel (prefetching screen tasks) against the 4-wavefront one, three workgroups per CU
+    for B in (48, 64, 72):
+        x = torch.from_numpy(synth.make_segments(B, N, d, n_events=192, seed=1002)).cuda()
+        nat.tune(nat.MP_TUNE_PERSIST_WORKERS, 768)
+        row = []
+        for v in (4, 3, 4, 3):
+            nat.tune(nat.MP_TUNE_PERSIST_VARIANT, v)
+            r = rate(B, x, nat.MP_FLAG_FFT_PERSISTENT)
+            st = nat.persist_stats()
+            row.append(f"variant {v}: {r:6.0f} k (task {st['task_ticks'] / max(st['tasks'], 1) / 100:5.1f} us, select {st['select_ticks'] / max(st['selects'], 1) / 100:5.1f} us)")
+        nat.tune(nat.MP_TUNE_PERSIST_VARIANT, 0)
+        print(f"B{B}: " + " | ".join(row), flush=True)

@@ -672,7 +672,7 @@ def test_init_streams_and_capture_in_a_thread_without_a_pool(oracle):
 
 
 def test_which_form_the_default_schedule_takes():
-    """flags = 0 on MP_PATH_FFT: the persistent form from 40 segments up where the shape allows it (here 1024-point
+    """flags = 0 on MP_PATH_FFT: the persistent form from 24 segments up where the shape allows it (here 1024-point
     transforms), sub-batches on forked streams (from 48 segments) where it does not (512-point transforms) or when a
     flag names another form, one stream below; mp_last_schedule() tells which.  All bit-identical."""
     d = synth.make_dictionary(64, 256, seed=61)
@@ -681,7 +681,7 @@ def test_which_form_the_default_schedule_takes():
     streams = min(4, nat.init_streams())
     ref = nat.encode(x, du, 7, path=nat.MP_PATH_FFT, flags=nat.MP_FLAG_NO_OVERLAP)
     assert nat.last_schedule() == 1
-    for flags, n, want in ((0, 56, -1), (0, 40, -1), (0, 39, 1), (nat.MP_FLAG_FFT_PERSISTENT, 5, -1), (nat.MP_FLAG_FFT_NO_PERSISTENT, 56, streams),
+    for flags, n, want in ((0, 56, -1), (0, 24, -1), (0, 23, 1), (nat.MP_FLAG_FFT_PERSISTENT, 5, -1), (nat.MP_FLAG_FFT_NO_PERSISTENT, 56, streams),
                            (nat.flag_groups(2), 56, min(2, streams)), (nat.MP_FLAG_FFT_FUSED, 56, streams)):
         out = nat.encode(x[:n], du, 7, path=nat.MP_PATH_FFT, flags=flags)
         assert nat.last_schedule() == want, (flags, n, nat.last_schedule())
