@@ -109,8 +109,8 @@ int mp_profile_enable(int every);
 #define MP_TUNE_PERSIST_WORKERS 7 /* persistent form: workgroups of the launch (0 = heuristic: 2, 3 or 4 per CU by the
                                      number of screen tasks the batch can have in flight)                          */
 #define MP_TUNE_PERSIST_SELECTS 8 /* persistent form: how many of them are select workers (0 = min(segments, 64))    */
-#define MP_TUNE_PERSIST_VARIANT 9 /* persistent form: 3 / 4 = the kernel compiled for three (168 VGPRs, pair spectra requested
-                                     one transform ahead) / four wavefronts per SIMD; 0 = three when the grid allows  */
+#define MP_TUNE_PERSIST_VARIANT 9 /* persistent form: 3 / 4 = the kernel compiled for three (168 VGPRs) / four (128) wavefronts per
+                                     SIMD; 0 = three when the grid is at most three workgroups per CU                 */
 int mp_tune(int key, double value);
 int mp_profile_read(double *ms, int64_t *count);
 

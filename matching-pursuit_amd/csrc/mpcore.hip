@@ -1078,6 +1078,10 @@ __global__ __launch_bounds__(1024) void dictionary_update_level_kernel(
 // ------------------------------------------------------------------------------------------------
 #include "mpfft.inc"
 
+// bytes of the persistent form's control block + ticket lines + queue (mppersist.inc: PersistCtl <= 256, 512 lines of 64,
+// B (K - 1) + 2 entries of 128); carve() reserves them, fft_setup clears them
+inline size_t persist_ctl_bytes(int64_t B, int K) { return 256 + 512 * 64 + ((size_t)B * (K - 1) + 2) * 128; }
+
 constexpr int MP_FLAG_FFT_PERSISTENT_BIT = 65536;  // (= MP_FLAG_FFT_PERSISTENT, include/mpcore.h)
 thread_local int last_schedule = 0;  // mp_last_schedule(): -1 persistent, 1 one stream, n >= 2 sub-batches
 
@@ -1156,7 +1160,7 @@ Workspace carve(const Geom &g, int path, char *base, int K = 0) {
             // persistent schedule (mppersist.inc): queue + one window record per (segment, step >= 2)
             if (quarters && !f.split && f.logM >= 10 && f.logM <= 12 && K >= 2) {
                 const size_t qn = (size_t)g.B * (K - 1) + 2;
-                size_t o_pc = take(256 + 512 * 64 + qn * 128);  // PersistCtl + group words + PersistEntry[qn] (mppersist.inc)
+                size_t o_pc = take(persist_ctl_bytes(g.B, K));  // PersistCtl + ticket lines + PersistEntry[qn] (mppersist.inc)
                 size_t o_xr = take((size_t)g.B * (K > 2 ? K - 2 : 0) * ((size_t)f.M + 16) * sizeof(cpx));
                 w.pctl = base + o_pc;
                 w.xrec = reinterpret_cast<cpx *>(base + o_xr);
@@ -1387,20 +1391,33 @@ TauModel fft_tau(int logM) {
 // Zero `bytes` (a multiple of 4, 4-byte aligned) on the stream, as a kernel: a captured encode then holds kernel nodes
 // only (a replayed hipGraph whose persistent launch depends on the cleared queue must not depend on how the runtime
 // orders its memset nodes -- seen: correct on the first replay, into fresh zero pages, stale state on the second).
-__global__ void clear_words_kernel(unsigned *__restrict__ p, size_t n) {
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) p[i] = 0u;
+struct ClearList {   // up to 8 ranges cleared by ONE launch
+    unsigned *p[8];
+    size_t n[8];      // words
+    int count = 0;
+    void add(void *ptr, size_t bytes) {
+        if (ptr && bytes >= 4 && count < 8) { p[count] = static_cast<unsigned *>(ptr); n[count] = bytes / 4; ++count; }
+    }
+};
+__global__ void clear_words_kernel(ClearList c) {
+    for (int r = 0; r < c.count; ++r) {
+        unsigned *p = c.p[r];
+        const size_t n = c.n[r];
+        for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) p[i] = 0u;
+    }
 }
-int clear_async(void *p, size_t bytes, hipStream_t st) {
-    const size_t n = bytes / 4;
-    if (!n) return MP_OK;
-    const size_t blocks = std::min<size_t>((n + 255) / 256, 4096);
-    hipLaunchKernelGGL(clear_words_kernel, dim3((unsigned)blocks), dim3(256), 0, st, static_cast<unsigned *>(p), n);
+int clear_async(const ClearList &c, hipStream_t st) {
+    size_t most = 0;
+    for (int r = 0; r < c.count; ++r) most = std::max(most, c.n[r]);
+    if (!most) return MP_OK;
+    const size_t blocks = std::min<size_t>((most + 255) / 256, 4096);
+    hipLaunchKernelGGL(clear_words_kernel, dim3((unsigned)blocks), dim3(256), 0, st, c);
     HIP_TRY(hipGetLastError());
     return MP_OK;
 }
 
 // once per encode, whole batch, on the caller's stream: twiddles, pair spectra, cleared keys / flags
-int fft_setup(const Geom &g, const Workspace &w, const float *du, int flags, hipStream_t st) {
+int fft_setup(const Geom &g, const Workspace &w, const float *du, int flags, int K, hipStream_t st) {
     FftGeom f;
     if (!make_fft_geom(g, &f))
         return fail(MP_ERR_UNSUPPORTED, "MP_PATH_FFT: atoms longer than 10859 samples need MP_PATH_INCREMENTAL%s");
@@ -1409,10 +1426,14 @@ int fft_setup(const Geom &g, const Workspace &w, const float *du, int flags, hip
     const int64_t n_cells = (int64_t)g.NBLK * g.NAT;
     const int npairs = g.NAT * f.NPT;
     int rc;
-    if ((rc = clear_async(w.overflow, (size_t)g.B * sizeof(int), st))) return rc;
-    if ((rc = clear_async(w.ekeys, (size_t)g.B * (MAXCONT + 1) * sizeof(u64), st))) return rc;
-    if ((rc = clear_async(w.bsum, (size_t)g.B * g.NBLK * 2 * sizeof(unsigned), st))) return rc;
-    if ((rc = clear_async(w.keys, (size_t)g.B * n_cells * sizeof(u64), st))) return rc;
+    ClearList cl;   // everything the encode needs zeroed, in one launch
+    cl.add(w.overflow, (size_t)g.B * sizeof(int));
+    cl.add(w.ekeys, (size_t)g.B * (MAXCONT + 1) * sizeof(u64));
+    cl.add(w.bsum, (size_t)g.B * g.NBLK * 2 * sizeof(unsigned));
+    cl.add(w.keys, (size_t)g.B * n_cells * sizeof(u64));
+    cl.add(w.dscale, sizeof(float));
+    if (w.pctl && K >= 2) cl.add(w.pctl, persist_ctl_bytes(g.B, K));   // the persistent form's control block and queue
+    if ((rc = clear_async(cl, st))) return rc;
     if (f.split) {  // long atoms: two half-size transforms per M-point transform (mpfft.inc)
         constexpr int LH = SPLIT_LOGH;
         const int H = f.M / 2;
@@ -1824,14 +1845,13 @@ static int encode_impl(const float *signal, int64_t B, int64_t N, const float *d
     }
     rc = stage_inputs(g, w, path, signal, dict_unit, rule.lead, st);
     if (rc) return rc;
-    if (path == MP_PATH_FFT && (rc = fft_setup(g, w, dict_unit, flags, st))) return rc;
+    if (path == MP_PATH_FFT && (rc = fft_setup(g, w, dict_unit, flags, K, st))) return rc;
     if (path == MP_PATH_FFT) {
         // the screen's bound |fm| <= ||window|| * max_a ||d_a||: 1 for the unit-norm dictionary this entry point
         // is documented for, but measured rather than trusted (and the convolution model's atoms are raw)
         FftGeom f;
         if (!make_fft_geom(g, &f)) return fail(MP_ERR_UNSUPPORTED, "MP_PATH_FFT: atom too long%s");
         const TauModel tm = fft_tau(f.logM);
-        if ((rc = clear_async(w.dscale, sizeof(float), st))) return rc;
         hipLaunchKernelGGL(max_row_norm_kernel, dim3((unsigned)((A + 3) / 4)), dim3(256), 0, st, dict_unit, A, L, w.dscale,
                            tm.chain_w, tm.fft_w);
         HIP_TRY(hipGetLastError());
@@ -1870,8 +1890,7 @@ static int encode_impl(const float *signal, int64_t B, int64_t N, const float *d
             rc = launch_persistent(g, f, w, dict_unit, rule, K, fft_tau(f.logM).tau, out_atom, out_lag, out_gain, st);
             g_prof.end(st);
             if (rc) return rc;
-            hipLaunchKernelGGL(persist_error_kernel, dim3((unsigned)((B + 255) / 256)), dim3(256), 0, st, w.pctl, w.overflow, (int)B);
-            hipLaunchKernelGGL(fft_mark_overflow_kernel, dim3((unsigned)B), dim3(64), 0, st, w.overflow, out_gain, K);
+            hipLaunchKernelGGL(persist_mark_kernel, dim3((unsigned)B), dim3(64), 0, st, w.pctl, w.overflow, out_gain, (int)B, K);
             HIP_TRY(hipGetLastError());
             if (out_residual) {
                 dim3 grid((unsigned)((N + 255) / 256 < 1024 ? (N + 255) / 256 : 1024), (unsigned)B);
