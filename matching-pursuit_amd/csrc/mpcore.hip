@@ -1158,10 +1158,13 @@ Workspace carve(const Geom &g, int path, char *base, int K = 0) {
             w.bsum = reinterpret_cast<unsigned *>(base + o_bs);
             if (quarters) w.subk = reinterpret_cast<float *>(base + o_sk);
             // persistent schedule (mppersist.inc): queue + one window record per (segment, step >= 2)
-            if (quarters && !f.split && f.logM >= 10 && f.logM <= 12 && K >= 2) {
+            // (one write-once window record per segment and step: not for batches whose records would pass 2 GiB --
+            //  those run launch per step)
+            const size_t xrec_bytes = (size_t)g.B * (K > 2 ? K - 2 : 0) * ((size_t)f.M + 16) * sizeof(cpx);
+            if (quarters && !f.split && f.logM >= 10 && f.logM <= 12 && K >= 2 && xrec_bytes <= ((size_t)2 << 30)) {
                 const size_t qn = (size_t)g.B * (K - 1) + 2;
                 size_t o_pc = take(persist_ctl_bytes(g.B, K));  // PersistCtl + ticket lines + PersistEntry[qn] (mppersist.inc)
-                size_t o_xr = take((size_t)g.B * (K > 2 ? K - 2 : 0) * ((size_t)f.M + 16) * sizeof(cpx));
+                size_t o_xr = take(xrec_bytes);
                 w.pctl = base + o_pc;
                 w.xrec = reinterpret_cast<cpx *>(base + o_xr);
             }
