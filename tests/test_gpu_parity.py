@@ -696,6 +696,44 @@ def test_which_form_the_default_schedule_takes():
     assert nat.last_schedule() == 1
 
 
+def test_two_threads_run_the_persistent_form_concurrently(oracle):
+    """Two persistent launches at the same time, from two host threads on two streams: each is sized for the whole
+    GPU, so their workgroups share it -- whichever are resident draw the tickets; nobody waits for a particular
+    workgroup -- and both must come out bit-identical to the oracle with no wait given up."""
+    import threading
+    d = synth.make_dictionary(64, 256, seed=61)
+    du_np = oracle.unit_norm(d)
+    du = torch.from_numpy(du_np).to(DEV)
+    xs = [synth.make_segments(40, 6000, d, n_events=10, seed=63 + i) for i in range(2)]
+    want = [oracle.encode(x, du_np, 8) for x in xs]
+    got, scheds, errors = [None, None], [None, None], []
+    go = threading.Barrier(2)
+
+    def work(i):
+        try:
+            stream = torch.cuda.Stream(DEV)
+            xd = torch.from_numpy(xs[i]).to(DEV)
+            stream.wait_stream(torch.cuda.current_stream(DEV))
+            go.wait()
+            with torch.cuda.stream(stream):
+                for _ in range(6):
+                    out = nat.encode(xd, du, 8, path=nat.MP_PATH_FFT)
+                scheds[i] = nat.last_schedule()
+                stream.synchronize()
+            got[i] = [t.cpu().numpy() for t in out]
+        except Exception as e:  # noqa: BLE001
+            errors.append(repr(e))
+
+    threads = [threading.Thread(target=work, args=(i,)) for i in range(2)]
+    [t.start() for t in threads]
+    [t.join() for t in threads]
+    assert not errors, errors
+    assert scheds == [-1, -1]
+    for i in range(2):
+        assert np.array_equal(got[i][0], want[i]["atom"]) and np.array_equal(got[i][1], want[i]["lag"]), i
+        assert np.array_equal(got[i][2], want[i]["gain"]) and np.array_equal(got[i][3], want[i]["residual"]), i
+
+
 def test_persistent_form_replayed_from_a_graph(oracle):
     """The persistent form captured into a hipGraph and replayed: every replay bit-identical to the oracle.  The
     launch depends on its queue having been cleared by THIS replay (the first replay runs into fresh zero pages, so
