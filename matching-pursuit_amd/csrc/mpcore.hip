@@ -1311,13 +1311,13 @@ struct Rule {
 };
 
 int stage_inputs(const Geom &g, const Workspace &w, int path, const float *signal, const float *du,
-                 int64_t lead, hipStream_t st) {
+                 int64_t lead, hipStream_t st, bool want_image = true) {
     {
         dim3 grid((unsigned)((g.Ns + 255) / 256 < 1024 ? (g.Ns + 255) / 256 : 1024), (unsigned)g.B);
         hipLaunchKernelGGL(init_residual_kernel, grid, dim3(256), 0, st, signal, g.N, g.Ns, lead, w.res);
         HIP_TRY(hipGetLastError());
     }
-    if (path != MP_PATH_NAIVE) {
+    if (path != MP_PATH_NAIVE && want_image) {   // the MFMA kernels' dictionary image
         int64_t total = (int64_t)g.NAT * g.NCH * g.KC * g.TA;
         unsigned blocks = (unsigned)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
         hipLaunchKernelGGL(dict_image_kernel, dim3(blocks), dim3(256), 0, st, du, g.A, g.L, g.TA, g.KC,
@@ -1846,7 +1846,8 @@ static int encode_impl(const float *signal, int64_t B, int64_t N, const float *d
         dict_unit = w.drev;
         rule = Rule{dict_in, (int)(L - 1), 1, L - 1};
     }
-    rc = stage_inputs(g, w, path, signal, dict_unit, rule.lead, st);
+    // (MP_PATH_FFT reads the dictionary image only when its refinement runs on the MFMA cell code)
+    rc = stage_inputs(g, w, path, signal, dict_unit, rule.lead, st, path != MP_PATH_FFT || (flags & MP_FLAG_REFINE_MFMA));
     if (rc) return rc;
     if (path == MP_PATH_FFT && (rc = fft_setup(g, w, dict_unit, flags, K, st))) return rc;
     if (path == MP_PATH_FFT) {
