@@ -106,11 +106,9 @@ int mp_profile_enable(int every);
 #define MP_TUNE_AUDIT 4
 #define MP_TUNE_PERSIST_SHARDS 6 /* MP_FLAG_FFT_PERSISTENT: number of ticket counters the screen workers are split over
                                     (0 = heuristic: one per ~512 workers)                                          */
-#define MP_TUNE_PERSIST_WORKERS 7 /* persistent form: workgroups of the launch (0 = heuristic: 2, 3 or 4 per CU by the
+#define MP_TUNE_PERSIST_WORKERS 7 /* persistent form: workgroups of the launch (0 = heuristic: 2 or 3 per CU by the
                                      number of screen tasks the batch can have in flight)                          */
 #define MP_TUNE_PERSIST_SELECTS 8 /* persistent form: how many of them are select workers (0 = min(segments, 64))    */
-#define MP_TUNE_PERSIST_VARIANT 9 /* persistent form: 3 / 4 = the kernel compiled for three (168 VGPRs) / four (128) wavefronts per
-                                     SIMD; 0 = three when the grid is at most three workgroups per CU                 */
 int mp_tune(int key, double value);
 int mp_profile_read(double *ms, int64_t *count);
 

@@ -1783,7 +1783,6 @@ int mp_tune(int key, double value) {
     if (key == MP_TUNE_PERSIST_SHARDS && value >= 0) { persist_shards.store((int)value); return MP_OK; }
     if (key == MP_TUNE_PERSIST_WORKERS && value >= 0) { persist_workers.store((int)value); return MP_OK; }
     if (key == MP_TUNE_PERSIST_SELECTS && value >= 0) { persist_selects.store((int)value); return MP_OK; }
-    if (key == MP_TUNE_PERSIST_VARIANT && (value == 0 || value == 3 || value == 4)) { persist_variant.store((int)value); return MP_OK; }
     return fail(MP_ERR_ARG, "mp_tune: unknown key or bad value%s");
 }
 

@@ -30,7 +30,6 @@ MP_TUNE_AUDIT = 4
 MP_TUNE_PERSIST_SHARDS = 6
 MP_TUNE_PERSIST_WORKERS = 7
 MP_TUNE_PERSIST_SELECTS = 8
-MP_TUNE_PERSIST_VARIANT = 9
 MP_FLAG_GROUPS_SHIFT = 20
 MP_FLAG_NO_OVERLAP = 4096
 MP_FLAG_FFT_NO_QUARTER = 8192

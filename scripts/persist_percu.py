@@ -24,32 +24,20 @@ if mode == "percu":     # workgroups per CU against the batch size, and the laun
     for B in (16, 24, 32, 40, 48, 56, 64, 72, 80, 96, 112, 128):
         x = torch.from_numpy(synth.make_segments(B, N, d, n_events=192, seed=1002)).cuda()
         row = []
-        for pcu in (2, 3, 4):
+        for pcu in (2, 3):
             nat.tune(nat.MP_TUNE_PERSIST_WORKERS, 256 * pcu)
             row.append(f"{pcu}/CU {rate(B, x, nat.MP_FLAG_FFT_PERSISTENT):6.0f} k")
         nat.tune(nat.MP_TUNE_PERSIST_WORKERS, 0)
         row.append(f"heuristic {rate(B, x, nat.MP_FLAG_FFT_PERSISTENT):6.0f} k")
         row.append(f"per step, one stream {rate(B, x, nat.MP_FLAG_NO_OVERLAP):6.0f} k, sub-batches {rate(B, x, nat.MP_FLAG_FFT_NO_PERSISTENT):6.0f} k")
         print(f"B{B:4d}: " + " | ".join(row), flush=True)
-elif mode != "variant": # one batch size: total workgroups x select workers
+else:                   # one batch size: total workgroups x select workers
     B = int(mode)
     x = torch.from_numpy(synth.make_segments(B, N, d, n_events=192, seed=1002)).cuda()
     for nsel in (32, 48, 64):
         nat.tune(nat.MP_TUNE_PERSIST_SELECTS, nsel)
         row = []
-        for workers in (576, 640, 704, 768, 832, 896, 1024):
+        for workers in (512, 576, 640, 704, 768):
             nat.tune(nat.MP_TUNE_PERSIST_WORKERS, workers)
             row.append(f"{workers}: {rate(B, x, nat.MP_FLAG_FFT_PERSISTENT):6.0f} k")
         print(f"B{B} select workers {nsel}: " + " | ".join(row), flush=True)
-if mode == "variant":   # the 3-wavefront kernel (prefetching screen tasks) against the 4-wavefront one, three workgroups per CU
-    for B in (48, 64, 72):
-        x = torch.from_numpy(synth.make_segments(B, N, d, n_events=192, seed=1002)).cuda()
-        nat.tune(nat.MP_TUNE_PERSIST_WORKERS, 768)
-        row = []
-        for v in (4, 3, 4, 3):
-            nat.tune(nat.MP_TUNE_PERSIST_VARIANT, v)
-            r = rate(B, x, nat.MP_FLAG_FFT_PERSISTENT)
-            st = nat.persist_stats()
-            row.append(f"variant {v}: {r:6.0f} k (task {st['task_ticks'] / max(st['tasks'], 1) / 100:5.1f} us, select {st['select_ticks'] / max(st['selects'], 1) / 100:5.1f} us)")
-        nat.tune(nat.MP_TUNE_PERSIST_VARIANT, 0)
-        print(f"B{B}: " + " | ".join(row), flush=True)
