@@ -236,7 +236,7 @@ def roofline_persistent(prof, n_segments, steps):
         "bound": "valu", "achieved": round(achieved, 1), "peak": round(PEAK_VALU_GINSTR, 1),
         "unit": "G wave64-instructions/s (packed fp32 issue)",
         "frac": round(achieved / PEAK_VALU_GINSTR, 4), "traffic": traffic,
-        "kernel": "fft_persistent_kernel<11,2,3> (queue of radix-16 Stockham screen tasks + select workers, three "
+        "kernel": "fft_persistent_kernel<11,2> (queue of radix-16 Stockham screen tasks + select workers, three "
                   "workgroups per CU, one launch for steps 1 .. K-1)",
         "launches": steps, "avg_launch_ms": round(avg_s * 1e3, 5),
         "timed_with_events": {"persistent_launch": n_p, "step0_screen": n_full, "sampling": "every launch"},

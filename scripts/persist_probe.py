@@ -20,4 +20,4 @@ for B, shards in [(b, sh) for b in (32, 64, 128, 256) for sh in shard_list]:
     torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / 8
     st = nat.persist_stats()
     print(f"B{B:3d} shards {shards:3d}: one {dt1 * 1e3:6.2f} ms, 8 in a row {dt * 1e3:6.2f} ms = {B * K / dt:9.0f} seg-it/s | per task {st['task_ticks'] / max(st['tasks'], 1) / 100:7.1f} us, per select "
-          f"{st['select_ticks'] / max(st['selects'], 1) / 100:7.1f} us {st['select_phase_us']}, polls {st['polls']}", flush=True)
+          f"{st['select_ticks'] / max(st['selects'], 1) / 100:7.1f} us {st['select_phase_us']}, between tasks {st['idle_ticks'] / max(st['tasks'], 1) / 100:5.1f} us per task, polls {st['polls']}", flush=True)
