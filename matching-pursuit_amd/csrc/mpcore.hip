@@ -22,6 +22,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <type_traits>
 #include <atomic>
 #include <mutex>
 #include <vector>

@@ -792,6 +792,21 @@ def test_config1_full_size_default_schedule(oracle):
     assert np.array_equal(gain[:4, :16].cpu().numpy(), want["gain"])
 
 
+def test_default_schedule_repeats_bit_identically_at_full_size():
+    """The same full-size encode twenty times on the library default: every repetition bit-identical to the one-stream
+    form.  (A hazard that depends on timing -- an LDS read consumed before its wait, a hand-off read early -- shows up
+    as a different pick in a different segment every few repetitions, not in a single run.)"""
+    A, L, N, B, K = 512, 512, 32768, 64, 64
+    d = synth.make_dictionary(A, L, seed=1000)
+    x = torch.from_numpy(synth.make_segments(B, N, d, n_events=3 * K, seed=1002)).to(DEV)
+    du = nat.unit_norm(torch.from_numpy(d).to(DEV))
+    ref = nat.encode(x, du, K, path=nat.MP_PATH_FFT, flags=nat.MP_FLAG_NO_OVERLAP)
+    for rep in range(20):
+        out = nat.encode(x, du, K, path=nat.MP_PATH_FFT)
+        assert all(torch.equal(p, q) for p, q in zip(out, ref)), rep
+    assert nat.last_schedule() == -1 and nat.persist_stats()["error"] == 0
+
+
 def test_config3_full_size_default_schedule():
     """configs[3]: 4096 x 2048 dictionary, B = 128 segments of 131072 samples, K = 256 on the default schedule
     (FFT screen, whole-cell select with block summaries): no overflow marks, decode(events) + residual = signal,
