@@ -686,6 +686,12 @@ def test_which_form_the_default_schedule_takes():
         out = nat.encode(x[:n], du, 7, path=nat.MP_PATH_FFT, flags=flags)
         assert nat.last_schedule() == want, (flags, n, nat.last_schedule())
         assert all(torch.equal(p, q[:n]) for p, q in zip(out, ref)), (flags, n)
+    for K in (2, 3):                                   # the shortest runs the one-launch form takes: one and two steps in the launch
+        out = nat.encode(x, du, K, path=nat.MP_PATH_FFT)
+        assert nat.last_schedule() == -1 and nat.persist_stats()["error"] == 0
+        one = nat.encode(x, du, K, path=nat.MP_PATH_FFT, flags=nat.MP_FLAG_NO_OVERLAP)
+        assert all(torch.equal(p, q) for p, q in zip(out, one)), K
+        assert all(torch.equal(p[:, :K], q[:, :K]) for p, q in zip(out[:3], ref[:3])), K
     nat.encode(x, du, 1, path=nat.MP_PATH_FFT)        # a single step has no steps 1 .. K-1 to put in one launch
     assert nat.last_schedule() == streams
     d2 = synth.make_dictionary(40, 96, seed=51)       # 512-point transforms: outside the persistent form
