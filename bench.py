@@ -266,7 +266,7 @@ def roofline_persistent(prof, n_segments, steps):
     return out
 
 
-def ran_persistent(prof, steps):
+def ran_persistent():
     """True if the encodes just timed took the persistent form (mp_last_schedule)."""
     return nat.last_schedule() == -1
 
@@ -421,7 +421,7 @@ def main():
     atom, lag, gain, residual = [t.cpu().numpy() for t in out]
     seg_its = world * B_PER_GPU * K_ITERS * args.steps
     if path == nat.MP_PATH_FFT:
-        roof = (roofline_persistent if ran_persistent(prof, args.steps) else roofline_fft)(prof, B_PER_GPU, args.steps)
+        roof = (roofline_persistent if ran_persistent() else roofline_fft)(prof, B_PER_GPU, args.steps)
     else:
         roof = roofline_from(prof, algorithmic_flops(lag, path), args.steps)
     rdb = 20 * np.log10(np.linalg.norm(residual, axis=-1) / np.linalg.norm(x_host, axis=-1))
@@ -461,7 +461,7 @@ def main():
                 vlag = vout[1].cpu().numpy()
                 same = all(torch.equal(p, q) for p, q in zip(vout, out))
                 if other == nat.MP_PATH_FFT:
-                    vroof = (roofline_persistent if ran_persistent(vprof, vsteps) else roofline_fft)(vprof, B_PER_GPU, vsteps)
+                    vroof = (roofline_persistent if ran_persistent() else roofline_fft)(vprof, B_PER_GPU, vsteps)
                 else:
                     vroof = roofline_from(vprof, algorithmic_flops(vlag, other), vsteps)
                 line["variants"][name] = {
