@@ -702,6 +702,33 @@ def test_which_form_the_default_schedule_takes():
     assert nat.last_schedule() == 1
 
 
+def test_persistent_form_with_scarce_and_odd_worker_counts(oracle):
+    """The queue must not depend on how many workgroups serve it: one select worker for fifty segments, three screen
+    workers in all, more select workers than segments, a grid larger than what is resident -- all bit-identical to the
+    oracle, no wait given up (mp_tune(MP_TUNE_PERSIST_WORKERS / _SELECTS / _SHARDS))."""
+    d = synth.make_dictionary(64, 256, seed=61)
+    du_np = oracle.unit_norm(d)
+    du = torch.from_numpy(du_np).to(DEV)
+    x_host = synth.make_segments(50, 6000, d, n_events=10, seed=62)
+    want = oracle.encode(x_host, du_np, 7)
+    x = torch.from_numpy(x_host).to(DEV)
+    try:
+        for workers, selects, shards in ((4, 1, 1), (20, 3, 2), (300, 64, 7), (768, 200, 0), (100000, 0, 64), (0, 0, 0)):
+            nat.tune(nat.MP_TUNE_PERSIST_WORKERS, workers)
+            nat.tune(nat.MP_TUNE_PERSIST_SELECTS, selects)
+            nat.tune(nat.MP_TUNE_PERSIST_SHARDS, shards)
+            a, l, g, r = nat.encode(x, du, 7, path=nat.MP_PATH_FFT)
+            torch.cuda.synchronize()
+            st = nat.persist_stats()
+            assert nat.last_schedule() == -1 and st["error"] == 0 and st["finished"] == 50, (workers, selects, shards, st)
+            assert np.array_equal(a.cpu().numpy(), want["atom"]) and np.array_equal(l.cpu().numpy(), want["lag"]), (workers, selects)
+            assert np.array_equal(g.cpu().numpy(), want["gain"]) and np.array_equal(r.cpu().numpy(), want["residual"]), (workers, selects)
+    finally:
+        nat.tune(nat.MP_TUNE_PERSIST_WORKERS, 0)
+        nat.tune(nat.MP_TUNE_PERSIST_SELECTS, 0)
+        nat.tune(nat.MP_TUNE_PERSIST_SHARDS, 0)
+
+
 def test_two_threads_run_the_persistent_form_concurrently(oracle):
     """Two persistent launches at the same time, from two host threads on two streams: each is sized for the whole
     GPU, so their workgroups share it -- whichever are resident draw the tickets; nobody waits for a particular
