@@ -109,6 +109,9 @@ int mp_profile_enable(int every);
 #define MP_TUNE_PERSIST_WORKERS 7 /* persistent form: workgroups of the launch (0 = heuristic: 2 or 3 per CU by the
                                      number of screen tasks the batch can have in flight)                          */
 #define MP_TUNE_PERSIST_SELECTS 8 /* persistent form: how many of them are select workers (0 = min(segments, 64))    */
+#define MP_TUNE_LAZY_MARGIN 10    /* lazy screen (mp_encode_lazy_f32): a tile is skipped when its dirty cells' widened upper
+                                     bounds stay below margin x the best lower bound of the untouched blocks (0 < margin <= 1,
+                                     default 0.7; any value is exact, smaller = fewer skips and fewer stale contenders)      */
 int mp_tune(int key, double value);
 int mp_profile_read(double *ms, int64_t *count);
 
@@ -199,6 +202,26 @@ float mp_stream_pair_ratio(int q0, int q1);
  * to run side by side (>= 1; sub-batches need >= 2), or a negative error (e.g. `stream` is being captured). */
 int mp_init_streams(void *stream);
 
+/*
+ * mp_encode_f32 with the dictionary's COHERENCE TABLE (the lazy screen of MP_PATH_FFT's persistent form).
+ * coherence[a * NAT + t], NAT = ceil(A / 32): an upper bound on |sum_j d_a[j] d_b[j + s]| over the 32 atoms b of tile t and
+ * all shifts s, for the unit-norm dictionary passed (the caller computes it -- e.g. from mp_feature_map_f32 of the atoms --
+ * and may keep it as long as the dictionary does not change; it must be an upper bound in exact arithmetic).  After an
+ * event (a, g) a cell changes by at most |g| coherence: tiles none of whose dirty cells can then reach the best lower bound
+ * of the untouched blocks keep their (widened) bounds and skip their transforms.  Same events bit for bit; NULL, or any
+ * form other than the persistent one, is mp_encode_f32.  (Not for the convolution model.)
+ */
+int mp_encode_lazy_f32(const float *signal, int64_t B, int64_t N, const float *dict_unit, int64_t A, int64_t L, int K,
+                       int path, int flags, const float *coherence, int64_t *out_atom, int64_t *out_lag, float *out_gain,
+                       float *out_residual, void *workspace, size_t workspace_bytes, void *stream);
+
+/* The coherence table mp_encode_lazy_f32 takes, computed on the device: out[A][ceil(A / 32)] (one full-pass FFT screen of
+ * the atoms against the dictionary: ~0.3 ms at 512 x 512).  Exists where the lazy screen does (1024- to 4096-point
+ * transforms: 63 <= L <= 1302); mp_coherence_workspace_bytes returns 0 otherwise. */
+size_t mp_coherence_workspace_bytes(int64_t A, int64_t L);
+int mp_coherence_f32(const float *dict_unit, int64_t A, int64_t L, float *out, void *workspace, size_t workspace_bytes,
+                     void *stream);
+
 /* Which form the calling thread's last mp_encode_f32 / mp_encode_conv_f32 took: -1 = the persistent form (step 0, then
  * one launch for steps 1 .. K-1), 1 = one kernel sequence per step on the caller's stream, n >= 2 = n sub-batches on
  * forked internal streams; 0 before the first encode.  No device work. */
@@ -207,7 +230,8 @@ int mp_last_schedule(void);
 /* Debug: statistics of the last MP_FLAG_FFT_PERSISTENT launch on the current device, summed over its workgroups --
  * out16[0..2] = 100 MHz wall-clock ticks spent idle (polling the queue), in screen tasks, in selects; [3..5] = tasks,
  * selects, polls; [6] = error flag, [7] = segments finished; [8..12] = ticks of the selects' phases (acquire, scan,
- * quarters + chains, event + next window, transform + stores), [13] = selects counted.  Synchronises the device. */
+ * quarters + chains, event + next window, transform + stores), [13] = selects counted, [14] = screen tasks answered without
+ * a transform (lazy screen).  Synchronises the device. */
 int mp_persist_stats(uint64_t *out16);
 
 /* Debug (MP_TUNE_AUDIT): the largest |screen - exact| / eps over all cells audited since the last read, their

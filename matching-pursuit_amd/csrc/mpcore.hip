@@ -95,6 +95,7 @@ constexpr int WAVES = 4;            // wavefronts per workgroup
 constexpr int KC_MAX = 512;         // atom samples staged in LDS per chunk
 constexpr int MAXCONT = 32;         // FFT path: inexact contender cells per segment per iteration
 constexpr int MP_FLAG_INTERNAL_ONE_STREAM = 1 << 30;  // set by encode_impl: the batch is not split
+constexpr int MP_FLAG_INTERNAL_COHERENCE = 1 << 29;   // set by mp_coherence_f32: |.| screen only
 constexpr int64_t QUARTER_MAX_CELLS = 16384;  // FFT path: segments this small use the quarter-cell select kernel
 constexpr int64_t FUSED_MIN_CELLS = 65536;    // FFT path: from here the whole-cell one-kernel select, with block summaries
 
@@ -1559,6 +1560,17 @@ int fft_iteration(const Geom &g, const Workspace &w, const float *du, int K, int
                 const bool seg_fast = (size_t)g.NAT * f.NPT * f.M * sizeof(cpx) > (size_t)16 << 20;
                 const unsigned gwp = nw * (16 / (C::SLOTS * pps));
                 const dim3 grid = seg_fast ? dim3((unsigned)g.B, gwp, g.NAT) : dim3(gwp, g.NAT, (unsigned)g.B);
+                if (flags & MP_FLAG_INTERNAL_COHERENCE) {   // mp_coherence_f32: cell maxima of |correlation|, nothing after the screen
+                    constexpr int LC = LS <= 12 ? LS : 12;  // (only sizes the persistent form takes get here)
+                    auto kabs = (fft_screen_kernel<LC, true>);
+                    if ((rc = fft_lds_attr(kabs, lds_s))) return rc;
+                    hipLaunchKernelGGL(kabs, grid, dim3(C::WG), lds_s, st, w.xspec, w.pspec, w.tw, dirty, w.wnorm, w.keys, w.ceps,
+                                       g.N, g.A, g.NBLK, g.NAT, f.V, f.NW, tau, pps, (int)seg_fast, (float *)nullptr,
+                                       (unsigned *)nullptr);
+                    HIP_TRY(hipGetLastError());
+                    g_prof.end(st);
+                    return MP_OK;
+                }
                 if ((rc = fft_lds_attr(fft_screen_kernel<LS>, lds_s))) return rc;
                 hipLaunchKernelGGL(fft_screen_kernel<LS>, grid, dim3(C::WG), lds_s, st, w.xspec, w.pspec, w.tw, dirty,
                                    w.wnorm, w.keys, w.ceps, g.N, g.A, g.NBLK, g.NAT, f.V, f.NW, tau, pps, (int)seg_fast, subk, bsum);
@@ -1776,6 +1788,73 @@ size_t mp_workspace_bytes(int64_t B, int64_t N, int64_t A, int64_t L, int K, int
     return b64 > b32 ? b64 : b32;
 }
 
+// ---- the dictionary's coherence table (lazy screen) ---------------------------------------------------------------------
+// Row a of the pseudo-batch is atom a between L - 1 zeros on either side: its correlation with atom b at lag n is
+// sum_j d_a[j] d_b[j + (L - 1 - n)], every shift of the pair for n = 0 .. 2L - 2.  One full-pass FFT screen of the A rows
+// with |.| maxima (A * A / 2 pair transforms per window), then per (row, tile) the maximum over the blocks of
+// approx + 2 eps (eps bounds |screen - chain|, and the chain's own rounding is within eps too).
+__global__ void coherence_rows_kernel(const float *__restrict__ d, int64_t A, int64_t L, int64_t Nrow, float *__restrict__ rows) {
+    const int64_t a = blockIdx.y;
+    for (int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; j < Nrow; j += (int64_t)gridDim.x * blockDim.x)
+        rows[a * Nrow + j] = (j >= L - 1 && j < 2 * L - 1) ? d[a * L + (j - (L - 1))] : 0.0f;
+}
+__global__ void coherence_reduce_kernel(const u64 *__restrict__ keys, const float *__restrict__ ceps, int NBLK, int NAT,
+                                        float *__restrict__ out) {
+    const int64_t a = blockIdx.x;
+    for (int t = threadIdx.x; t < NAT; t += blockDim.x) {
+        float m = 0.0f;
+        for (int blk = 0; blk < NBLK; ++blk) {
+            const int64_t c = (a * NBLK + blk) * NAT + t;
+            const u64 kv = keys[c];
+            if (kv) m = fmaxf(m, unord_f32((unsigned)(kv >> 32)) + 2.0f * ceps[c]);
+        }
+        out[a * NAT + t] = m;
+    }
+}
+static bool coherence_geom(int64_t A, int64_t L, Geom *g, FftGeom *f) {
+    if (A <= 0 || L <= 0) return false;
+    *g = make_geom_for(A, 3 * L - 2, A, L, MP_PATH_FFT, 0);
+    return make_fft_geom(*g, f) && !f->split && f->logM >= 10 && f->logM <= 12;
+}
+size_t mp_coherence_workspace_bytes(int64_t A, int64_t L) {
+    Geom g;
+    FftGeom f;
+    if (!coherence_geom(A, L, &g, &f)) return 0;
+    return carve(g, MP_PATH_FFT, nullptr, 1).bytes + 256 + (size_t)A * (3 * L - 2) * sizeof(float);
+}
+int mp_coherence_f32(const float *dict_unit, int64_t A, int64_t L, float *out, void *workspace, size_t workspace_bytes,
+                     void *stream) {
+    Geom g;
+    FftGeom f;
+    if (!dict_unit || !out || !workspace) return fail(MP_ERR_ARG, "mp_coherence_f32: null argument%s");
+    if (!coherence_geom(A, L, &g, &f))
+        return fail(MP_ERR_UNSUPPORTED, "mp_coherence_f32: the lazy screen exists for 1024- to 4096-point transforms only%s");
+    if (reinterpret_cast<uintptr_t>(workspace) % 256) return fail(MP_ERR_WORKSPACE, "workspace not 256-byte aligned%s");
+    if (workspace_bytes < mp_coherence_workspace_bytes(A, L)) return fail(MP_ERR_WORKSPACE, "workspace too small%s");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    Workspace w = carve(g, MP_PATH_FFT, static_cast<char *>(workspace), 1);
+    const int64_t Nrow = 3 * L - 2;
+    float *rows = reinterpret_cast<float *>(static_cast<char *>(workspace) + ((w.bytes + 255) / 256) * 256);
+    hipLaunchKernelGGL(coherence_rows_kernel, dim3((unsigned)((Nrow + 255) / 256), (unsigned)A), dim3(256), 0, st, dict_unit, A, L,
+                       Nrow, rows);
+    HIP_TRY(hipGetLastError());
+    int rc;
+    if ((rc = stage_inputs(g, w, MP_PATH_FFT, rows, dict_unit, 0, st, false))) return rc;
+    if ((rc = fft_setup(g, w, dict_unit, 0, 1, st))) return rc;
+    const TauModel tm = fft_tau(f.logM);
+    hipLaunchKernelGGL(max_row_norm_kernel, dim3((unsigned)((A + 3) / 4)), dim3(256), 0, st, dict_unit, A, L, w.dscale, tm.chain_w,
+                       tm.fft_w);
+    HIP_TRY(hipGetLastError());
+    const Rule rule{dict_unit, 0, 0, 0};
+    g_prof.arm(-1);
+    if ((rc = fft_iteration(g, w, dict_unit, 1, 0, MP_FLAG_INTERNAL_COHERENCE | MP_FLAG_INTERNAL_ONE_STREAM, nullptr, nullptr, nullptr,
+                            rule, st)))
+        return rc;
+    hipLaunchKernelGGL(coherence_reduce_kernel, dim3((unsigned)A), dim3(64), 0, st, w.keys, w.ceps, g.NBLK, g.NAT, out);
+    HIP_TRY(hipGetLastError());
+    return MP_OK;
+}
+
 int mp_tune(int key, double value) {
     if (key == MP_TUNE_TAU && value >= 0.0) { tau_override.store((float)value); return MP_OK; }  // 0: back to the model
     if (key == MP_TUNE_SCREEN_PPS) { screen_pps_override.store((int)value); return MP_OK; }
@@ -1784,6 +1863,7 @@ int mp_tune(int key, double value) {
     if (key == MP_TUNE_PERSIST_SHARDS && value >= 0) { persist_shards.store((int)value); return MP_OK; }
     if (key == MP_TUNE_PERSIST_WORKERS && value >= 0) { persist_workers.store((int)value); return MP_OK; }
     if (key == MP_TUNE_PERSIST_SELECTS && value >= 0) { persist_selects.store((int)value); return MP_OK; }
+    if (key == MP_TUNE_LAZY_MARGIN && value > 0.0 && value <= 1.0) { persist_margin.store((float)value); return MP_OK; }
     return fail(MP_ERR_ARG, "mp_tune: unknown key or bad value%s");
 }
 
@@ -1820,7 +1900,7 @@ int mp_unit_norm_f32(const float *d, int64_t A, int64_t L, float eps, float *out
 static int encode_impl(const float *signal, int64_t B, int64_t N, const float *dict_in, int64_t A,
                        int64_t L, int K, int path, int flags, int64_t *out_atom, int64_t *out_lag,
                        float *out_gain, float *out_residual, void *workspace, size_t workspace_bytes,
-                       void *stream, bool conv_model) {
+                       void *stream, bool conv_model, const float *coherence = nullptr) {
     int rc = check_shape(B, N, A, L, K);
     if (rc) return rc;
     flags &= ~MP_FLAG_INTERNAL_ONE_STREAM;  // ours to set
@@ -1891,7 +1971,8 @@ static int encode_impl(const float *signal, int64_t B, int64_t N, const float *d
             g_prof.arm(0);
             if ((rc = fft_iteration(g, w, dict_unit, K, 0, f0, out_atom, out_lag, out_gain, rule, st))) return rc;
             g_prof.begin(PROF_CORR_INC, st);  // (one span around the whole launch: steps 1 .. K-1)
-            rc = launch_persistent(g, f, w, dict_unit, rule, K, fft_tau(f.logM).tau, out_atom, out_lag, out_gain, st);
+            rc = launch_persistent(g, f, w, dict_unit, rule, K, fft_tau(f.logM).tau, out_atom, out_lag, out_gain, st,
+                                   conv_model ? nullptr : coherence);
             g_prof.end(st);
             if (rc) return rc;
             hipLaunchKernelGGL(persist_mark_kernel, dim3((unsigned)B), dim3(64), 0, st, w.pctl, w.overflow, out_gain, (int)B, K);
@@ -1992,6 +2073,14 @@ int mp_encode_f32(const float *signal, int64_t B, int64_t N, const float *dict_u
                   void *stream) {
     return encode_impl(signal, B, N, dict_unit, A, L, K, path, flags, out_atom, out_lag, out_gain, out_residual,
                        workspace, workspace_bytes, stream, false);
+}
+
+int mp_encode_lazy_f32(const float *signal, int64_t B, int64_t N, const float *dict_unit, int64_t A,
+                       int64_t L, int K, int path, int flags, const float *coherence, int64_t *out_atom, int64_t *out_lag,
+                       float *out_gain, float *out_residual, void *workspace, size_t workspace_bytes,
+                       void *stream) {
+    return encode_impl(signal, B, N, dict_unit, A, L, K, path, flags, out_atom, out_lag, out_gain, out_residual,
+                       workspace, workspace_bytes, stream, false, coherence);
 }
 
 int mp_encode_conv_f32(const float *signal, int64_t B, int64_t N, const float *atoms, int64_t A,
@@ -2276,12 +2365,15 @@ int mp_audit_read(float *max_ratio, int64_t *cells, float *max_quarter_ratio, in
 int mp_persist_stats(uint64_t *out8 /* [16] */) {
     if (!out8) return fail(MP_ERR_ARG, "mp_persist_stats: null output%s");
     HIP_TRY(hipDeviceSynchronize());
-    HIP_TRY(hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_persist_stats), 8 * sizeof(uint64_t)));
+    uint64_t nine[9];
+    HIP_TRY(hipMemcpyFromSymbol(nine, HIP_SYMBOL(g_persist_stats), 9 * sizeof(uint64_t)));
+    for (int i = 0; i < 8; ++i) out8[i] = nine[i];
     {   // the selects' phase ticks behind them: [8..12] acquire, scan, quarters + chains, event + window, transform + stores; [13] selects
         const uint64_t zero[8] = {0, 0, 0, 0, 0, 0, 0, 0};
         HIP_TRY(hipMemcpyFromSymbol(out8 + 8, HIP_SYMBOL(g_persist_phase), 8 * sizeof(uint64_t)));
         HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(g_persist_phase), zero, sizeof(zero)));
     }
+    out8[14] = nine[8];   // screen tasks answered without a transform (lazy screen)
     return MP_OK;
 }
 

@@ -30,6 +30,7 @@ MP_TUNE_AUDIT = 4
 MP_TUNE_PERSIST_SHARDS = 6
 MP_TUNE_PERSIST_WORKERS = 7
 MP_TUNE_PERSIST_SELECTS = 8
+MP_TUNE_LAZY_MARGIN = 10
 MP_FLAG_GROUPS_SHIFT = 20
 MP_FLAG_NO_OVERLAP = 4096
 MP_FLAG_FFT_NO_QUARTER = 8192
@@ -46,7 +47,8 @@ EXPORTS = (
     "mp_profile_enable", "mp_profile_read", "mp_fft_c2c_f32", "mp_encode_conv_f32", "mp_tune",
     "mp_dictionary_update_f32", "mp_lcn_workspace_bytes", "mp_encode_lcn_f32", "mp_conv_model_backward_f32",
     "mp_stream_pair_ratio", "mp_init_streams", "mp_audit_read", "mp_dictionary_levels_host",
-    "mp_dictionary_update_levels_f32", "mp_persist_stats", "mp_last_schedule",
+    "mp_dictionary_update_levels_f32", "mp_persist_stats", "mp_last_schedule", "mp_encode_lazy_f32",
+    "mp_coherence_f32", "mp_coherence_workspace_bytes",
 )
 
 
@@ -85,6 +87,11 @@ def lib():
         L.mp_encode_f32.argtypes = [vp, i64, i64, vp, i64, i64, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                     vp, vp, vp, vp, vp, ctypes.c_size_t, vp]
         L.mp_encode_conv_f32.argtypes = L.mp_encode_f32.argtypes
+        L.mp_coherence_workspace_bytes.restype = ctypes.c_size_t
+        L.mp_coherence_workspace_bytes.argtypes = [i64, i64]
+        L.mp_coherence_f32.argtypes = [vp, i64, i64, vp, vp, ctypes.c_size_t, vp]
+        L.mp_encode_lazy_f32.argtypes = [vp, i64, i64, vp, i64, i64, ctypes.c_int, ctypes.c_int, ctypes.c_int, vp,
+                                         vp, vp, vp, vp, vp, ctypes.c_size_t, vp]
         L.mp_feature_map_f32.argtypes = [vp, i64, i64, vp, i64, i64, vp, vp, ctypes.c_size_t, vp]
         L.mp_scatter_f32.argtypes = [vp, vp, vp, vp, i64, vp, i64, i64, vp, i64, i64, vp]
         L.mp_scatter_rows_f32.argtypes = [vp, vp, vp, i64, i64, vp, i64, i64, vp]
@@ -158,6 +165,7 @@ def persist_stats():
     k = ("idle_ticks", "task_ticks", "select_ticks", "tasks", "selects", "polls", "error", "finished")
     out = {n: int(buf[i]) for i, n in enumerate(k)}
     n = max(int(buf[13]), 1)
+    out["skipped"] = int(buf[14])
     out["select_phase_us"] = {p: round(int(buf[8 + i]) / 100.0 / n, 2)
                               for i, p in enumerate(("acquire", "scan", "chains", "event_window", "transform_stores"))}
     return out
@@ -230,11 +238,86 @@ def encode_checked(signal, dict_unit, n_steps, flags=0, want_residual=True):
     return atom, lag, gain, residual
 
 
-def encode(signal, dict_unit, n_steps, path=MP_PATH_INCREMENTAL, flags=0, want_residual=True, conv_model=False):
+def coherence_table(dict_unit, chunk=128, exact=False):
+    """The dictionary's coherence table for the lazy screen (mp_encode_lazy_f32): [A, NAT] f32 on the device,
+    entry (a, t) >= max over the 32 atoms b of tile t and all shifts s of |sum_j d_a[j] d_b[j + s]|.
+    Default: mp_coherence_f32 -- one full-pass FFT screen of the atoms against the dictionary, |.| maxima plus the
+    screen's bound (~0.3 ms at the headline dictionary); where that does not exist (transform sizes the lazy screen
+    does not cover) or with exact=True: exact correlations of every atom, placed in a zero row, with the whole dictionary
+    (mp_feature_map_f32), plus the fp32 chain's worst-case rounding u L (~5 ms)."""
+    dict_unit = _f32(dict_unit)
+    _require_cuda(dict_unit)
+    A, L = dict_unit.shape
+    nbytes = 0 if exact else lib().mp_coherence_workspace_bytes(A, L)
+    if nbytes:
+        dev = dict_unit.device
+        out = torch.empty((A, (A + 31) // 32), dtype=torch.float32, device=dev)
+        ws = torch.empty(nbytes + 256, dtype=torch.uint8, device=dev)
+        off = (-ws.data_ptr()) % 256
+        with torch.cuda.device(dev):
+            rc = lib().mp_coherence_f32(_ptr(dict_unit), A, L, _ptr(out), ctypes.c_void_p(ws.data_ptr() + off), nbytes,
+                                        _stream(dict_unit))
+        _check(rc, "mp_coherence_f32")
+        ws.record_stream(torch.cuda.current_stream(dev))
+        return out
+    nat_tiles = (A + 31) // 32
+    rows = torch.zeros((min(chunk, A), 3 * L - 2), dtype=torch.float32, device=dict_unit.device)
+    out = torch.empty((A, nat_tiles), dtype=torch.float32, device=dict_unit.device)
+    pad = nat_tiles * 32 - A
+    for a0 in range(0, A, chunk):
+        n = min(chunk, A - a0)
+        rows.zero_()
+        rows[:n, L - 1:2 * L - 1] = dict_unit[a0:a0 + n]
+        fm = feature_map(rows[:n], dict_unit)[..., :2 * L - 1]          # [n, A, 2L-1]: every shift of every pair
+        m = fm.abs().amax(dim=-1)                                       # [n, A]
+        if pad:
+            m = torch.nn.functional.pad(m, (0, pad))
+        out[a0:a0 + n] = m.view(n, nat_tiles, 32).amax(dim=-1)
+    return out + float(L) * 5.9604645e-8 * float(dict_unit.norm(dim=-1).max()) ** 2
+
+
+_coherence_cache = {}   # (data_ptr, version, shape, device) -> weakref(tensor) after its first sighting, (table, tensor) after
+
+
+def cached_coherence(dict_unit, owner=None):
+    """The coherence table of a dictionary TENSOR that has been encoded against before, else None.  The table is computed
+    (mp_coherence_f32, ~0.45 ms at 512 x 512) at the second sighting of the same live tensor object with the same storage
+    and version counter -- so a dictionary that is re-normalised or updated every call (a training loop; the temporaries
+    of sparse_code) never pays for it, and one that is encoded against again and again (a fixed dictionary: the streaming
+    encoder, an EncodePlan, bench.py) pays once.  The cache holds the tensor, so its storage cannot be handed to another
+    one; torch's in-place operations bump the version counter (do not write into a cached dictionary behind torch's
+    back).  At most 8 dictionaries are remembered; shapes the lazy screen does not cover return None."""
+    import weakref
+    owner = dict_unit if owner is None else owner   # the caller's tensor object (encode() passes the one it was given:
+    A, L = dict_unit.shape                           # its own fp32 / contiguous view is a new object every call)
+    if lib().mp_coherence_workspace_bytes(A, L) == 0:
+        return None
+    key = (dict_unit.data_ptr(), owner._version, tuple(dict_unit.shape), str(dict_unit.device))
+    ent = _coherence_cache.get(key)
+    if isinstance(ent, tuple):
+        return ent[0]
+    if ent is not None and ent() is owner:
+        _coherence_cache[key] = (coherence_table(dict_unit), owner)
+        return _coherence_cache[key][0]
+    if len(_coherence_cache) >= 8:
+        _coherence_cache.pop(next(iter(_coherence_cache)))
+    _coherence_cache[key] = weakref.ref(owner)
+    return None
+
+
+LAZY_MIN_BATCH = 24   # (the persistent form's threshold: below it the table would not be used)
+
+
+def encode(signal, dict_unit, n_steps, path=MP_PATH_INCREMENTAL, flags=0, want_residual=True, conv_model=False,
+           coherence=None):
     """signal [B,N] f32 cuda, dict_unit [A,L] f32 cuda -> (atom[B,K] i64, lag[B,K] i64,
     gain[B,K] f32, residual[B,N] f32 | None), all on signal.device, asynchronous.
-    conv_model=True: mp_encode_conv_f32 (the analysis loop of mp.py's model; `dict_unit` = raw atoms)."""
+    conv_model=True: mp_encode_conv_f32 (the analysis loop of mp.py's model; `dict_unit` = raw atoms).
+    coherence: the dictionary's coherence_table() -> mp_encode_lazy_f32 (MP_PATH_FFT's persistent form skips the
+    transforms of tiles an event cannot have lifted into contention; same events).  None: cached_coherence() decides
+    (a dictionary tensor seen before gets its table); False: never."""
     signal = _f32(signal)
+    dict_owner = dict_unit
     dict_unit = _f32(dict_unit)
     _require_cuda(signal, dict_unit)
     B, N = signal.shape
@@ -251,19 +334,31 @@ def encode(signal, dict_unit, n_steps, path=MP_PATH_INCREMENTAL, flags=0, want_r
         for b0 in range(0, B, FFT_MAX_BATCH):
             sl = slice(b0, min(b0 + FFT_MAX_BATCH, B))
             a, l, g, r = encode(signal[sl], dict_unit, K, path=path, flags=flags, want_residual=want_residual,
-                                conv_model=conv_model)
+                                conv_model=conv_model, coherence=coherence)
             atom[sl], lag[sl], gain[sl] = a, l, g
             if want_residual:
                 residual[sl] = r
         return atom, lag, gain, residual
+    if coherence is None and path == MP_PATH_FFT and not conv_model and B >= LAZY_MIN_BATCH and K >= 8 and \
+            not (int(flags) & ~MP_FLAG_FFT_PERSISTENT):
+        if dict_unit.data_ptr() == dict_owner.data_ptr():   # (a converted copy is a temporary: nothing to remember)
+            coherence = cached_coherence(dict_unit, dict_owner)   # (None until the same dictionary tensor comes a second time)
     nbytes = workspace_bytes(B, N, A, L, K, path)
     ws = torch.empty(nbytes + 256, dtype=torch.uint8, device=dev)
     off = (-ws.data_ptr()) % 256
     with torch.cuda.device(dev):
-        fn = lib().mp_encode_conv_f32 if conv_model else lib().mp_encode_f32
-        rc = fn(_ptr(signal), B, N, _ptr(dict_unit), A, L, K, int(path), int(flags),
-                                 _ptr(atom), _ptr(lag), _ptr(gain), _ptr(residual),
-                                 ctypes.c_void_p(ws.data_ptr() + off), nbytes, _stream(signal))
+        if coherence is not None and coherence is not False and not conv_model and path == MP_PATH_FFT:
+            coherence = _f32(coherence)
+            assert coherence.shape == (A, (A + 31) // 32) and coherence.device == dev
+            rc = lib().mp_encode_lazy_f32(_ptr(signal), B, N, _ptr(dict_unit), A, L, K, int(path), int(flags), _ptr(coherence),
+                                          _ptr(atom), _ptr(lag), _ptr(gain), _ptr(residual),
+                                          ctypes.c_void_p(ws.data_ptr() + off), nbytes, _stream(signal))
+            coherence.record_stream(torch.cuda.current_stream(dev))
+        else:
+            fn = lib().mp_encode_conv_f32 if conv_model else lib().mp_encode_f32
+            rc = fn(_ptr(signal), B, N, _ptr(dict_unit), A, L, K, int(path), int(flags),
+                    _ptr(atom), _ptr(lag), _ptr(gain), _ptr(residual),
+                    ctypes.c_void_p(ws.data_ptr() + off), nbytes, _stream(signal))
     _check(rc, "mp_encode_conv_f32" if conv_model else "mp_encode_f32")
     # the workspace must outlive the asynchronous kernels: tie it to the stream
     ws.record_stream(torch.cuda.current_stream(dev))

@@ -159,7 +159,7 @@ def test_hot_kernels_keep_their_register_budget():
     res = kr.kernel_resources()
     assert len(res) > 50
     screens = {n: r for n, r in res.items() if "17fft_screen_kernelILi" in n}
-    assert len(screens) == 5
+    assert len(screens) == 8   # 2^10 .. 2^14, and the |.| variant of 2^10 .. 2^12 (the coherence table's screen)
     for name, r in screens.items():
         assert r["spill"] == 0 and r["vgpr"] <= 128, (name, r)
     persistent = {n: r for n, r in res.items() if "correlate_persistent_kernel" in n}

@@ -702,6 +702,60 @@ def test_which_form_the_default_schedule_takes():
     assert nat.last_schedule() == 1
 
 
+def test_coherence_table_bounds_the_exact_one():
+    """mp_coherence_f32 (one |.| screen of the atoms against the dictionary) against the exact cross-correlations
+    (mp_feature_map_f32 of every atom in a zero row): never below them, and above by no more than the screen's bound."""
+    for A, L in ((64, 256), (100, 300), (40, 1000)):
+        du = nat.unit_norm(torch.from_numpy(synth.make_dictionary(A, L, seed=A + L)).to(DEV))
+        exact = nat.coherence_table(du, exact=True)
+        fast = nat.coherence_table(du)
+        assert fast.shape == exact.shape == (A, (A + 31) // 32)
+        assert (fast >= exact - 2e-4).all() and (fast <= exact + 5e-3).all(), (A, L, float((fast - exact).min()), float((fast - exact).max()))
+        own = torch.arange(A, device=DEV)
+        assert (fast[own, own // 32] >= 0.999).all()          # an atom against itself at shift 0
+    assert nat.lib().mp_coherence_workspace_bytes(64, 40) == 0     # 512-point transforms: no lazy screen
+
+
+def test_lazy_screen_is_bit_identical_to_the_oracle(oracle):
+    """mp_encode_lazy_f32: with the coherence table the persistent form skips the transforms of tiles an event cannot have
+    lifted into contention -- the events must not change, at any margin, and transforms must really be skipped."""
+    skipped = 0
+    try:
+        for A, L, N, B, K in ((64, 256, 6000, 30, 12), (100, 300, 9000, 50, 20), (96, 512, 12000, 40, 24), (40, 1000, 20000, 24, 10)):
+            d = synth.make_dictionary(A, L, seed=7 + A)
+            du_np = oracle.unit_norm(d)
+            du = torch.from_numpy(du_np).to(DEV)
+            x_host = synth.make_segments(B, N, d, n_events=2 * K, seed=9 + B)
+            want = oracle.encode(x_host, du_np, K)
+            x = torch.from_numpy(x_host).to(DEV)
+            mu = nat.coherence_table(du)
+            for margin in (1.0, 0.7, 0.3):
+                nat.tune(nat.MP_TUNE_LAZY_MARGIN, margin)
+                for rep in range(2):
+                    a, l, g, r = nat.encode(x, du, K, path=nat.MP_PATH_FFT, coherence=mu)
+                    torch.cuda.synchronize()
+                    st = nat.persist_stats()
+                    assert nat.last_schedule() == -1 and st["error"] == 0, (A, L, margin, st)
+                    keep = ~torch.isnan(g).any(dim=1).cpu().numpy()   # (a marked segment is re-encoded by the caller)
+                    assert keep.sum() >= B - 2
+                    assert np.array_equal(a.cpu().numpy()[keep], want["atom"][keep]) and np.array_equal(l.cpu().numpy()[keep], want["lag"][keep]), (A, L, margin)
+                    assert np.array_equal(g.cpu().numpy()[keep], want["gain"][keep]), (A, L, margin)
+                    assert np.array_equal(r.cpu().numpy()[keep], want["residual"][keep]), (A, L, margin)
+                    skipped += st["skipped"]
+        assert skipped > 1000
+        # the automatic form: the same dictionary TENSOR a second time gets its table; a flag that names another form does not
+        nat._coherence_cache.clear()
+        nat.encode(x, du, K, path=nat.MP_PATH_FFT)
+        assert nat.persist_stats()["skipped"] == 0
+        out = nat.encode(x, du, K, path=nat.MP_PATH_FFT)
+        assert nat.persist_stats()["skipped"] > 0
+        assert np.array_equal(out[0].cpu().numpy(), want["atom"]) and np.array_equal(out[2].cpu().numpy(), want["gain"])
+        nat.encode(x, du, K, path=nat.MP_PATH_FFT, coherence=False)
+        assert nat.persist_stats()["skipped"] == 0
+    finally:
+        nat.tune(nat.MP_TUNE_LAZY_MARGIN, 0.7)
+
+
 def test_persistent_form_with_scarce_and_odd_worker_counts(oracle):
     """The queue must not depend on how many workgroups serve it: one select worker for fifty segments, three screen
     workers in all, more select workers than segments, a grid larger than what is resident -- all bit-identical to the
