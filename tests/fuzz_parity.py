@@ -28,6 +28,7 @@ paths = [("fft", nat.MP_PATH_FFT, 0), ("fft_one_stream", nat.MP_PATH_FFT, nat.MP
          ("fft_persistent", nat.MP_PATH_FFT, nat.MP_FLAG_FFT_PERSISTENT), ("incremental", nat.MP_PATH_INCREMENTAL, 0)]
 bad = 0
 marked = 0
+lazy_skipped = 0
 for case in range(n_cases):
     A = int(rng.integers(1, 90)); L = int(rng.choice([5, 16, 33, 64, 100, 128, 250, 300, 512, 700, 1100]))
     N = int(rng.integers(max(L // 2, 40), 9000)); B = int(rng.choice([1, 2, 3, 7, 31, 32, 33, 45, 70])); K = int(rng.integers(1, 10))
@@ -61,8 +62,11 @@ for case in range(n_cases):
     want = mp_oracle.encode(x, du, K)
     gap = (want["top2"][..., 0] - want["top2"][..., 1]) / np.maximum(np.abs(want["top2"][..., 0]), 1e-30)
     xd = torch.from_numpy(x).cuda(); dud = torch.from_numpy(du).cuda()
-    for name, path, flags in paths:
-        a, l, g, r = nat.encode(xd, dud, K, path=path, flags=flags)
+    mu = nat.coherence_table(dud) if nat.lib().mp_coherence_workspace_bytes(A, L) else None
+    for name, path, flags in paths + ([("fft_lazy", nat.MP_PATH_FFT, nat.MP_FLAG_FFT_PERSISTENT)] if mu is not None and K >= 2 else []):
+        a, l, g, r = nat.encode(xd, dud, K, path=path, flags=flags, coherence=mu if name == "fft_lazy" else False)
+        if name == "fft_lazy":
+            lazy_skipped += nat.persist_stats()["skipped"]
         a, l, g, r = a.cpu().numpy(), l.cpu().numpy(), g.cpu().numpy(), r.cpu().numpy()
         nanrow = np.isnan(g).any(axis=1)
         marked += int(nanrow.sum())
@@ -114,5 +118,6 @@ if AUDIT:
     nat.tune(nat.MP_TUNE_AUDIT, 0)
     print("screen audit: largest |screen - exact| / eps", audit_worst, flush=True)
     bad += audit_worst["over_bound"]
-print("fuzz parity:", "OK" if bad == 0 else f"{bad} MISMATCHES", f"({marked} segment-runs marked as screen overflow)", flush=True)
+print("fuzz parity:", "OK" if bad == 0 else f"{bad} MISMATCHES", f"({marked} segment-runs marked as screen overflow; the lazy screen "
+      f"answered {lazy_skipped} tasks without a transform)", flush=True)
 sys.exit(1 if bad else 0)

@@ -16,7 +16,7 @@ for A, L, N, B, K in ((512, 256, 32768, 64, 32), (256, 1024, 32768, 64, 32), (51
     x = torch.from_numpy(synth.make_segments(B, N, d, n_events=min(3 * K, 96), seed=5 + B)).cuda()
     ref = nat.encode(x, du, K, path=nat.MP_PATH_FFT, flags=nat.MP_FLAG_NO_OVERLAP)
     torch.cuda.synchronize()
-    for name, path, flags in (("default", nat.MP_PATH_FFT, 0), ("one stream", nat.MP_PATH_FFT, nat.MP_FLAG_NO_OVERLAP),
+    for name, path, flags in (("default", nat.MP_PATH_FFT, 0), ("default again", nat.MP_PATH_FFT, 0), ("one stream", nat.MP_PATH_FFT, nat.MP_FLAG_NO_OVERLAP),
                               ("sub-batches", nat.MP_PATH_FFT, nat.MP_FLAG_FFT_NO_PERSISTENT),
                               ("quarter", nat.MP_PATH_FFT, nat.MP_FLAG_FFT_QUARTER | nat.MP_FLAG_NO_OVERLAP),
                               ("incremental", nat.MP_PATH_INCREMENTAL, 0)):
@@ -27,6 +27,7 @@ for A, L, N, B, K in ((512, 256, 32768, 64, 32), (256, 1024, 32768, 64, 32), (51
             miss += not all(torch.equal(p, q) for p, q in zip(out, ref))
         sched = nat.last_schedule()
         bad += miss
-        print(f"A{A} L{L} N{N} B{B} K{K} {name:12s} (schedule {sched:2d}): {miss} of {n} repetitions differ", flush=True)
+        print(f"A{A} L{L} N{N} B{B} K{K} {name:13s} (schedule {sched:2d}, lazy screen skipped {nat.persist_stats()['skipped'] if sched == -1 else 0:6d} tasks in the "
+              f"last one): {miss} of {n} repetitions differ", flush=True)
 print("soak:", "OK" if not bad else f"{bad} MISMATCHES", flush=True)
 sys.exit(1 if bad else 0)
