@@ -13,7 +13,8 @@ value = segment-iterations/s over all ranks, inputs resident in HBM, timed betwe
 barrier+synchronize pairs, max over ranks, on the library's default schedule for this shape (flags = 0:
 MP_PATH_FFT, FFT screen + exact refinement, events bit-identical to the direct paths, re-checked every run; from 48
 segments up the persistent form -- step 0 as separate kernels, steps 1 .. K-1 of the whole batch in ONE launch,
-csrc/mppersist.inc).  `variants` carries the launch-per-step forms of the same schedule (one stream: the form whose
+csrc/mppersist.inc -- and, from the second encode against the same dictionary tensor, its lazy screen: the coherence
+table it needs, 0.45 ms, is computed inside the timed region).  `variants` carries the launch-per-step forms of the same schedule (one stream: the form whose
 per-step screen kernel has its own roofline; four sub-batches on forked streams), the default's replay from a
 captured hipGraph (mpcore.EncodePlan) and the two direct-correlation (MFMA) schedules with their own rooflines.
 `roofline` is for the dominant kernel from HIP events recorded inside the timed region on the launch stream (the
