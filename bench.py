@@ -121,6 +121,9 @@ def pmc_traffic(kernel="correlate"):
     None if there is none."""
     import glob
     files = sorted(glob.glob(os.path.join(REPO, "profiles", "r*_summary.json")))
+    # the pass that profiled THIS kernel's schedule first (the persistent passes also contain the step-0 screen launches)
+    own = {"fft_persistent": "_persist_", "fft_screen": "_fft_", "correlate": "_mfma_"}.get(kernel, "")
+    files = [f for f in files if own not in os.path.basename(f)] + [f for f in files if own in os.path.basename(f)]
     for f in reversed(files):
         try:
             d = json.load(open(f))
