@@ -296,6 +296,8 @@ def cached_coherence(dict_unit, owner=None):
     ent = _coherence_cache.get(key)
     if isinstance(ent, tuple):
         return ent[0]
+    if torch.cuda.is_current_stream_capturing():
+        return None   # (never build the table inside a capture: it would live in the graph's private pool)
     if ent is not None and ent() is owner:
         _coherence_cache[key] = (coherence_table(dict_unit), owner)
         return _coherence_cache[key][0]
