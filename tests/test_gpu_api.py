@@ -635,3 +635,34 @@ def test_dictionary_update_fast_path_is_bit_identical_and_overlaps_are_detected(
     finally:
         nat.dictionary_update = real
     assert calls and torch.equal(slow, got)
+
+
+@pytest.mark.gpu
+def test_fixed_dictionary_gets_the_lazy_screen_through_the_api(oracle):
+    """A raw dictionary tensor handed to the drop-in surface again and again, unchanged: from its second call on the
+    surface keeps ONE normalised copy, from that copy's second encode on the encoder has its coherence table, and the
+    one-launch form skips transforms -- with the events of the first call, bit for bit.  A dictionary that is modified
+    in between (torch bumps its version counter) starts over."""
+    from mpcore import _native as nat
+    from mpcore import encode_packed, synth
+    import mpcore.matchingpursuit as mpm
+    nat._coherence_cache.clear()
+    mpm._dict_unit_cache.clear()
+    A, L, N, B, K = 64, 256, 6000, 30, 12
+    d_np = synth.make_dictionary(A, L, seed=5)
+    x_np = synth.make_segments(B, N, d_np, n_events=20, seed=6)
+    want = oracle.encode(x_np, oracle.unit_norm(d_np), K)
+    d = torch.from_numpy(d_np).to("cuda:0")
+    x = torch.from_numpy(x_np).to("cuda:0")
+    skipped = []
+    for call in range(5):
+        out = encode_packed(x, d, K)
+        torch.cuda.synchronize()
+        skipped.append(nat.persist_stats()["skipped"] if nat.last_schedule() == -1 else -1)
+        assert np.array_equal(out["atom"].cpu().numpy(), want["atom"]) and np.array_equal(out["gain"].cpu().numpy(), want["gain"]), call
+        assert np.array_equal(out["residual"].cpu().numpy(), want["residual"]), call
+    assert skipped[0] == 0 and skipped[1] == 0 and skipped[-1] > 0, skipped
+    d.mul_(1.0)                                   # same values, new version: treated as a new dictionary
+    encode_packed(x, d, K)
+    torch.cuda.synchronize()
+    assert nat.persist_stats()["skipped"] == 0
