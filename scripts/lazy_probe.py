@@ -18,7 +18,7 @@ for exact in (True, False):
 mu = mu_
 print(f"screen table - exact table: min {float((mu - mu_exact).min()):.2e} max {float((mu - mu_exact).max()):.2e} (must be >= about -1e-4: both bound the same quantity)", flush=True)
 margins = [float(v) for v in sys.argv[1:]] or [0.7]
-for B in (32, 64, 128):
+for B in (32, 48, 64, 96, 128):
     x = torch.from_numpy(synth.make_segments(B, N, d, n_events=192, seed=1002)).cuda()
     ref = nat.encode(x, du, K, path=nat.MP_PATH_FFT, flags=nat.MP_FLAG_NO_OVERLAP)
     torch.cuda.synchronize()
