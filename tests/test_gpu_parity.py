@@ -743,6 +743,7 @@ def test_lazy_screen_is_bit_identical_to_the_oracle(oracle):
                     assert np.array_equal(r.cpu().numpy()[keep], want["residual"][keep]), (A, L, margin)
                     skipped += st["skipped"]
         assert skipped > 1000
+        nat.tune(nat.MP_TUNE_LAZY_MARGIN, 0.7)
         # the automatic form: the same dictionary TENSOR a second time gets its table; a flag that names another form does not
         nat._coherence_cache.clear()
         nat.encode(x, du, K, path=nat.MP_PATH_FFT)
@@ -752,6 +753,16 @@ def test_lazy_screen_is_bit_identical_to_the_oracle(oracle):
         assert np.array_equal(out[0].cpu().numpy(), want["atom"]) and np.array_equal(out[2].cpu().numpy(), want["gain"])
         nat.encode(x, du, K, path=nat.MP_PATH_FFT, coherence=False)
         assert nat.persist_stats()["skipped"] == 0
+        # a batch large enough to pay for the table within one call gets it at the first sighting of its dictionary
+        nat._coherence_cache.clear()
+        d = synth.make_dictionary(200, 256, seed=77)
+        du2 = nat.unit_norm(torch.from_numpy(d).to(DEV))
+        x2 = torch.from_numpy(synth.make_segments(100, 6000, d, n_events=30, seed=78)).to(DEV)
+        first = nat.encode(x2, du2, 20, path=nat.MP_PATH_FFT)
+        assert nat.last_schedule() == -1 and nat.persist_stats()["skipped"] > 0
+        plain = nat.encode(x2, du2, 20, path=nat.MP_PATH_FFT, flags=nat.MP_FLAG_NO_OVERLAP)
+        keep = ~(torch.isnan(first[2]).any(dim=1) | torch.isnan(plain[2]).any(dim=1))   # (marked segments are re-encoded by the caller)
+        assert keep.sum() >= 90 and all(torch.equal(p[keep], q[keep]) for p, q in zip(first, plain))
     finally:
         nat.tune(nat.MP_TUNE_LAZY_MARGIN, 0.7)
 
