@@ -109,9 +109,15 @@ int mp_profile_enable(int every);
 #define MP_TUNE_PERSIST_WORKERS 7 /* persistent form: workgroups of the launch (0 = heuristic: 2 or 3 per CU by the
                                      number of screen tasks the batch can have in flight)                          */
 #define MP_TUNE_PERSIST_SELECTS 8 /* persistent form: how many of them are select workers (0 = min(segments, 64))    */
+#define MP_TUNE_LAZY_REUSE 12     /* lazy screen: how often a cell's bound may be widened before the cell is screened again the next
+                                     time it is dirty: 1 .. 4 (4 = no cap); 0 (default) = 4 up to 96 steps, 1 beyond           */
 #define MP_TUNE_LAZY_MARGIN 10    /* lazy screen (mp_encode_lazy_f32): a tile is skipped when its dirty cells' widened upper
                                      bounds stay below margin x the best lower bound of the untouched blocks (0 < margin <= 1,
                                      default 0.7; any value is exact, smaller = fewer skips and fewer stale contenders)      */
+#define MP_TUNE_LAZY_RADIUS 13    /* lazy screen: the run's floor is the K-th largest PEAK among the blocks' lower bounds after step
+                                     0 -- a block counts if it is the best within this many blocks either side; 0 (default) =
+                                     by atom length, 1 + ceil(max(0, L - 512) / 256).  Smaller = more skips, and stale contenders
+                                     (overflow marks) on signals whose maxima collapse within the run                          */
 int mp_tune(int key, double value);
 int mp_profile_read(double *ms, int64_t *count);
 

@@ -1082,7 +1082,7 @@ __global__ __launch_bounds__(1024) void dictionary_update_level_kernel(
 
 // bytes of the persistent form's control block + ticket lines + queue (mppersist.inc: PersistCtl <= 256, 512 lines of 64,
 // B (K - 1) + 2 entries of 128); carve() reserves them, fft_setup clears them
-inline size_t persist_ctl_bytes(int64_t B, int K) { return 256 + 512 * 64 + ((size_t)B * (K - 1) + 2) * 128; }
+inline size_t persist_ctl_bytes(int64_t B, int K) { return 256 + 512 * 64 + ((size_t)B * (K - 1) + 2) * 128 + (((size_t)B * 4 + 127) / 128) * 128; }  // (+ one floor per segment: lazy screen)
 
 constexpr int MP_FLAG_FFT_PERSISTENT_BIT = 65536;  // (= MP_FLAG_FFT_PERSISTENT, include/mpcore.h)
 thread_local int last_schedule = 0;  // mp_last_schedule(): -1 persistent, 1 one stream, n >= 2 sub-batches
@@ -1864,6 +1864,8 @@ int mp_tune(int key, double value) {
     if (key == MP_TUNE_PERSIST_WORKERS && value >= 0) { persist_workers.store((int)value); return MP_OK; }
     if (key == MP_TUNE_PERSIST_SELECTS && value >= 0) { persist_selects.store((int)value); return MP_OK; }
     if (key == MP_TUNE_LAZY_MARGIN && value > 0.0 && value <= 1.0) { persist_margin.store((float)value); return MP_OK; }
+    if (key == MP_TUNE_LAZY_REUSE && value >= 0 && value <= 4) { persist_reuse.store((int)value); return MP_OK; }
+    if (key == MP_TUNE_LAZY_RADIUS && value >= 0 && value <= 64) { persist_radius.store((int)value); return MP_OK; }
     return fail(MP_ERR_ARG, "mp_tune: unknown key or bad value%s");
 }
 
@@ -1971,8 +1973,15 @@ static int encode_impl(const float *signal, int64_t B, int64_t N, const float *d
             g_prof.arm(0);
             if ((rc = fft_iteration(g, w, dict_unit, K, 0, f0, out_atom, out_lag, out_gain, rule, st))) return rc;
             g_prof.begin(PROF_CORR_INC, st);  // (one span around the whole launch: steps 1 .. K-1)
-            rc = launch_persistent(g, f, w, dict_unit, rule, K, fft_tau(f.logM).tau, out_atom, out_lag, out_gain, st,
-                                   conv_model ? nullptr : coherence);
+            const float *mu = conv_model ? nullptr : coherence;
+            float *lbfloor = reinterpret_cast<float *>(w.pctl + 256 + 512 * 64 + ((size_t)B * (K - 1) + 2) * 128);
+            if (mu) {   // the lazy screen's floor: where this run's maxima are expected to end (mppersist.inc)
+                hipLaunchKernelGGL(persist_floor_kernel, dim3((unsigned)B), dim3(256), 0, st, (const unsigned *)w.bsum, g.NBLK, K, 
+                                   persist_radius.load(std::memory_order_relaxed) > 0 ? persist_radius.load(std::memory_order_relaxed)
+                                                                                  : (int)(1 + std::max<int64_t>(0, (L - 512 + 255) / 256)), lbfloor);
+                HIP_TRY(hipGetLastError());
+            }
+            rc = launch_persistent(g, f, w, dict_unit, rule, K, fft_tau(f.logM).tau, out_atom, out_lag, out_gain, st, mu, lbfloor);
             g_prof.end(st);
             if (rc) return rc;
             hipLaunchKernelGGL(persist_mark_kernel, dim3((unsigned)B), dim3(64), 0, st, w.pctl, w.overflow, out_gain, (int)B, K);

@@ -31,6 +31,8 @@ MP_TUNE_PERSIST_SHARDS = 6
 MP_TUNE_PERSIST_WORKERS = 7
 MP_TUNE_PERSIST_SELECTS = 8
 MP_TUNE_LAZY_MARGIN = 10
+MP_TUNE_LAZY_REUSE = 12
+MP_TUNE_LAZY_RADIUS = 13
 MP_FLAG_GROUPS_SHIFT = 20
 MP_FLAG_NO_OVERLAP = 4096
 MP_FLAG_FFT_NO_QUARTER = 8192

@@ -5,6 +5,7 @@ import os, sys, time
 import numpy as np, torch
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "matching-pursuit_amd"))
 from mpcore import _native as nat, synth
+if os.environ.get('LAZY_RADIUS'): nat.tune(nat.MP_TUNE_LAZY_RADIUS, int(os.environ['LAZY_RADIUS']))
 A, L, N, K = 512, 512, 32768, 64
 d = synth.make_dictionary(A, L, seed=1000)
 du = nat.unit_norm(torch.from_numpy(d).cuda())
@@ -18,11 +19,11 @@ for exact in (True, False):
 mu = mu_
 print(f"screen table - exact table: min {float((mu - mu_exact).min()):.2e} max {float((mu - mu_exact).max()):.2e} (must be >= about -1e-4: both bound the same quantity)", flush=True)
 margins = [float(v) for v in sys.argv[1:]] or [0.7]
-for B in (32, 48, 64, 96, 128):
+for B in ([64, 128] if os.environ.get('LAZY_RADIUS') else [32, 48, 64, 96, 128]):
     x = torch.from_numpy(synth.make_segments(B, N, d, n_events=192, seed=1002)).cuda()
     ref = nat.encode(x, du, K, path=nat.MP_PATH_FFT, flags=nat.MP_FLAG_NO_OVERLAP)
     torch.cuda.synchronize()
-    for name, co, mg in [("plain", False, 1.0), ("auto", None, 0.7)] + [(f"lazy {m:.2f}", mu, m) for m in margins]:
+    for name, co, mg in ([] if os.environ.get("LAZY_RADIUS") else [("plain", False, 1.0), ("auto", None, 0.7)]) + [(f"lazy {m:.2f}", mu, m) for m in margins]:
         nat.tune(nat.MP_TUNE_LAZY_MARGIN, mg)
         f = lambda: nat.encode(x, du, K, path=nat.MP_PATH_FFT, coherence=co)
         out = f(); torch.cuda.synchronize()

@@ -8,9 +8,12 @@ import numpy as np, torch
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(REPO, "matching-pursuit_amd"))
 from mpcore import _native as nat, synth
+if os.environ.get('LAZY_RADIUS'): nat.tune(nat.MP_TUNE_LAZY_RADIUS, int(os.environ['LAZY_RADIUS']))
 n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 40
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 99)
-bad = skipped = run = 0
+bad = skipped = run = marks_lazy = marks_ref = 0
+reuse = int(sys.argv[3]) if len(sys.argv) > 3 else 0
+nat.tune(nat.MP_TUNE_LAZY_REUSE, reuse)
 try:
     for case in range(n_cases):
         A = int(rng.integers(33, 260)); L = int(rng.choice([256, 300, 400, 512, 700, 1000, 1300]))
@@ -31,7 +34,7 @@ try:
             continue
         mu = nat.coherence_table(du)
         ref = nat.encode(xd, du, K, path=nat.MP_PATH_FFT, flags=nat.MP_FLAG_NO_OVERLAP, coherence=False)
-        margin = float(rng.choice([1.0, 0.7, 0.4]))
+        margin = float(rng.choice([0.7, 0.7, 0.4])) if len(sys.argv) > 3 else float(rng.choice([1.0, 0.7, 0.4]))
         nat.tune(nat.MP_TUNE_LAZY_MARGIN, margin)
         out = nat.encode(xd, du, K, path=nat.MP_PATH_FFT, flags=nat.MP_FLAG_FFT_PERSISTENT, coherence=mu)
         torch.cuda.synchronize()
@@ -39,6 +42,10 @@ try:
         keep = ~(torch.isnan(out[2]).any(dim=1) | torch.isnan(ref[2]).any(dim=1))
         same = all(torch.equal(p[keep], q[keep]) for p, q in zip(out, ref)) and st["error"] == 0 and nat.last_schedule() == -1
         skipped += st["skipped"]; run += st["tasks"]
+        ml, mr = int(torch.isnan(out[2]).any(dim=1).sum()), int(torch.isnan(ref[2]).any(dim=1).sum())
+        marks_lazy += ml; marks_ref += mr
+        if ml != mr and len(sys.argv) > 4:
+            print(f"   case {case} (kind {case % 5}): A{A} L{L} N{N} B{B} K{K} margin {margin}: marked {ml} lazy / {mr} without; skipped {st['skipped']} of {st['skipped'] + st['tasks']}", flush=True)
         if not same:
             bad += 1
             print(f"MISMATCH case {case}: A{A} L{L} N{N} B{B} K{K} margin {margin} stats {st}", flush=True)
@@ -46,5 +53,7 @@ try:
             print(f"{case + 1} cases, {bad} mismatches, {skipped} of {skipped + run} tasks skipped so far", flush=True)
 finally:
     nat.tune(nat.MP_TUNE_LAZY_MARGIN, 0.7)
+    nat.tune(nat.MP_TUNE_LAZY_REUSE, 0)
+print(f"segments marked: {marks_lazy} with the lazy screen (reuse {reuse}), {marks_ref} without", flush=True)
 print("lazy fuzz:", "OK" if not bad else f"{bad} MISMATCHES", f"({skipped} of {skipped + run} screen tasks answered without a transform)", flush=True)
 sys.exit(1 if bad else 0)
