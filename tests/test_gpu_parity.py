@@ -716,6 +716,23 @@ def test_coherence_table_bounds_the_exact_one():
     assert nat.lib().mp_coherence_workspace_bytes(64, 40) == 0     # 512-point transforms: no lazy screen
 
 
+def test_lazy_screen_leaves_no_stale_contenders_when_the_maxima_collapse():
+    """Fewer planted events than steps: once they are gone the running maximum falls to the noise floor.  Cells the lazy
+    screen left with widened bounds during the strong phase must not turn into contenders then (they overflowed every
+    segment's contender list before the floor rule of persist_floor_kernel): no segment marked, events identical."""
+    for A, L, N, B, K, ne in ((107, 700, 8086, 40, 34, 25), (211, 1300, 19485, 40, 38, 20), (216, 400, 22959, 24, 42, 30)):
+        d = synth.make_dictionary(A, L, seed=115)
+        du = nat.unit_norm(torch.from_numpy(d).to(DEV))
+        x = torch.from_numpy(synth.make_segments(B, N, d, n_events=ne, seed=215)).to(DEV)
+        ref = nat.encode(x, du, K, path=nat.MP_PATH_FFT, flags=nat.MP_FLAG_NO_OVERLAP, coherence=False)
+        assert not torch.isnan(ref[2]).any()
+        out = nat.encode(x, du, K, path=nat.MP_PATH_FFT, coherence=nat.coherence_table(du))
+        torch.cuda.synchronize()
+        assert nat.last_schedule() == -1 and nat.persist_stats()["error"] == 0
+        assert not torch.isnan(out[2]).any(), (A, L, int(torch.isnan(out[2]).any(dim=1).sum()))
+        assert all(torch.equal(p, q) for p, q in zip(out, ref)), (A, L)
+
+
 def test_lazy_screen_is_bit_identical_to_the_oracle(oracle):
     """mp_encode_lazy_f32: with the coherence table the persistent form skips the transforms of tiles an event cannot have
     lifted into contention -- the events must not change, at any margin, and transforms must really be skipped."""
