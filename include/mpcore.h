@@ -114,7 +114,7 @@ int mp_profile_enable(int every);
 #define MP_TUNE_LAZY_MARGIN 10    /* lazy screen (mp_encode_lazy_f32): a tile is skipped when its dirty cells' widened upper
                                      bounds stay below margin x the best lower bound of the untouched blocks (0 < margin <= 1,
                                      default 0.7; any value is exact, smaller = fewer skips and fewer stale contenders)      */
-#define MP_TUNE_LAZY_RADIUS 13    /* lazy screen: the run's floor is the K-th largest PEAK among the blocks' lower bounds after step
+#define MP_TUNE_LAZY_RADIUS 13    /* lazy screen: the run's floor is the (K + K/16 + 1)-th largest PEAK among the blocks' lower bounds after step
                                      0 -- a block counts if it is the best within this many blocks either side; 0 (default) =
                                      by atom length, 1 + ceil(max(0, L - 512) / 256).  Smaller = more skips, and stale contenders
                                      (overflow marks) on signals whose maxima collapse within the run                          */

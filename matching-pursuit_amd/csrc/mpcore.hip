@@ -1976,9 +1976,11 @@ static int encode_impl(const float *signal, int64_t B, int64_t N, const float *d
             const float *mu = conv_model ? nullptr : coherence;
             float *lbfloor = reinterpret_cast<float *>(w.pctl + 256 + 512 * 64 + ((size_t)B * (K - 1) + 2) * 128);
             if (mu) {   // the lazy screen's floor: where this run's maxima are expected to end (mppersist.inc)
-                hipLaunchKernelGGL(persist_floor_kernel, dim3((unsigned)B), dim3(256), 0, st, (const unsigned *)w.bsum, g.NBLK, K, 
-                                   persist_radius.load(std::memory_order_relaxed) > 0 ? persist_radius.load(std::memory_order_relaxed)
-                                                                                  : (int)(1 + std::max<int64_t>(0, (L - 512 + 255) / 256)), lbfloor);
+                // (rank K + K/16 + 1: now and then one event leaves two peaks; radius 1 + ceil(max(0, L - 512) / 256) blocks)
+                const int tuned = persist_radius.load(std::memory_order_relaxed);
+                const int radius = tuned > 0 ? tuned : (int)(1 + std::max<int64_t>(0, (L - 512 + 255) / 256));
+                hipLaunchKernelGGL(persist_floor_kernel, dim3((unsigned)B), dim3(256), 0, st, (const unsigned *)w.bsum, g.NBLK,
+                                   K + K / 16 + 1, radius, lbfloor);
                 HIP_TRY(hipGetLastError());
             }
             rc = launch_persistent(g, f, w, dict_unit, rule, K, fft_tau(f.logM).tau, out_atom, out_lag, out_gain, st, mu, lbfloor);

@@ -35,6 +35,7 @@ try:
         mu = nat.coherence_table(du)
         ref = nat.encode(xd, du, K, path=nat.MP_PATH_FFT, flags=nat.MP_FLAG_NO_OVERLAP, coherence=False)
         margin = float(rng.choice([0.7, 0.7, 0.4])) if len(sys.argv) > 3 else float(rng.choice([1.0, 0.7, 0.4]))
+        if os.environ.get('LAZY_MARGIN'): margin = float(os.environ['LAZY_MARGIN'])
         nat.tune(nat.MP_TUNE_LAZY_MARGIN, margin)
         out = nat.encode(xd, du, K, path=nat.MP_PATH_FFT, flags=nat.MP_FLAG_FFT_PERSISTENT, coherence=mu)
         torch.cuda.synchronize()
