@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""Persistent form: workgroups per CU (2 / 3 / 4) against the batch size -- 8 encodes in a row, headline dictionary."""
+"""Persistent form: workgroups per CU (2 / 3 / 4) against the batch size -- 8 encodes in a row, headline dictionary.
+LAZY=1 in the environment: with the lazy screen (the coherence table passed explicitly)."""
 import os, sys, time
 import numpy as np, torch
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -10,8 +11,9 @@ if len(sys.argv) > 1:
     A, L, N = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3])
 d = synth.make_dictionary(A, L, seed=1000)
 du = nat.unit_norm(torch.from_numpy(d).cuda())
+MU = nat.coherence_table(du) if os.environ.get('LAZY') else False   # LAZY=1: the persistent form with the lazy screen
 def rate(B, x, flags, n=8):
-    f = lambda: nat.encode(x, du, K, path=nat.MP_PATH_FFT, flags=flags)
+    f = lambda: nat.encode(x, du, K, path=nat.MP_PATH_FFT, flags=flags, coherence=(MU if flags == nat.MP_FLAG_FFT_PERSISTENT else False))
     f(); torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(n): f()
