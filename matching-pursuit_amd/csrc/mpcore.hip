@@ -1979,8 +1979,12 @@ static int encode_impl(const float *signal, int64_t B, int64_t N, const float *d
                 // (rank K + K/16 + 1: now and then one event leaves two peaks; radius 1 + ceil(max(0, L - 512) / 256) blocks)
                 const int tuned = persist_radius.load(std::memory_order_relaxed);
                 const int radius = tuned > 0 ? tuned : (int)(1 + std::max<int64_t>(0, (L - 512 + 255) / 256));
-                hipLaunchKernelGGL(persist_floor_kernel, dim3((unsigned)B), dim3(256), 0, st, (const unsigned *)w.bsum, g.NBLK,
-                                   K + K / 16 + 1, radius, lbfloor);
+                if (g.NBLK <= FLOOR_WAVE_MAXBLK)
+                    hipLaunchKernelGGL(persist_floor_wave_kernel, dim3((unsigned)B), dim3(64), 0, st, (const unsigned *)w.bsum, g.NBLK,
+                                       K + K / 16 + 1, radius, lbfloor);
+                else
+                    hipLaunchKernelGGL(persist_floor_kernel, dim3((unsigned)B), dim3(256), 0, st, (const unsigned *)w.bsum, g.NBLK,
+                                       K + K / 16 + 1, radius, lbfloor);
                 HIP_TRY(hipGetLastError());
             }
             rc = launch_persistent(g, f, w, dict_unit, rule, K, fft_tau(f.logM).tau, out_atom, out_lag, out_gain, st, mu, lbfloor);

@@ -720,7 +720,9 @@ def test_lazy_screen_leaves_no_stale_contenders_when_the_maxima_collapse():
     """Fewer planted events than steps: once they are gone the running maximum falls to the noise floor.  Cells the lazy
     screen left with widened bounds during the strong phase must not turn into contenders then (they overflowed every
     segment's contender list before the floor rule of persist_floor_kernel): no segment marked, events identical."""
-    for A, L, N, B, K, ne in ((107, 700, 8086, 40, 34, 25), (211, 1300, 19485, 40, 38, 20), (216, 400, 22959, 24, 42, 30)):
+    # (the last shape: more than 2048 blocks per segment -- the floor comes from the 256-thread form of the kernel)
+    for A, L, N, B, K, ne in ((107, 700, 8086, 40, 34, 25), (211, 1300, 19485, 40, 38, 20), (216, 400, 22959, 24, 42, 30),
+                              (64, 256, 140000, 24, 10, 30)):
         d = synth.make_dictionary(A, L, seed=115)
         du = nat.unit_norm(torch.from_numpy(d).to(DEV))
         x = torch.from_numpy(synth.make_segments(B, N, d, n_events=ne, seed=215)).to(DEV)
