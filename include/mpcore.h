@@ -116,7 +116,7 @@ int mp_profile_enable(int every);
                                      default 0.7; any value is exact, smaller = fewer skips and fewer stale contenders)      */
 #define MP_TUNE_LAZY_RADIUS 13    /* lazy screen: the run's floor is the (K + K/16 + 1)-th largest PEAK among the blocks' lower bounds after step
                                      0 -- a block counts if it is the best within this many blocks either side; 0 (default) =
-                                     by atom length, 1 + ceil(max(0, L - 512) / 256).  Smaller = more skips, and stale contenders
+                                     by atom length, 1 + ceil(max(0, L - 512) / 256); -1 = every block counts (tests: the floor comes out too high).  Smaller = more skips, and stale contenders
                                      (overflow marks) on signals whose maxima collapse within the run                          */
 int mp_tune(int key, double value);
 int mp_profile_read(double *ms, int64_t *count);

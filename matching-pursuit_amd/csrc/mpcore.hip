@@ -1865,7 +1865,7 @@ int mp_tune(int key, double value) {
     if (key == MP_TUNE_PERSIST_SELECTS && value >= 0) { persist_selects.store((int)value); return MP_OK; }
     if (key == MP_TUNE_LAZY_MARGIN && value > 0.0 && value <= 1.0) { persist_margin.store((float)value); return MP_OK; }
     if (key == MP_TUNE_LAZY_REUSE && value >= 0 && value <= 4) { persist_reuse.store((int)value); return MP_OK; }
-    if (key == MP_TUNE_LAZY_RADIUS && value >= 0 && value <= 64) { persist_radius.store((int)value); return MP_OK; }
+    if (key == MP_TUNE_LAZY_RADIUS && value >= -1 && value <= 64) { persist_radius.store((int)value); return MP_OK; }
     return fail(MP_ERR_ARG, "mp_tune: unknown key or bad value%s");
 }
 
@@ -1978,7 +1978,7 @@ static int encode_impl(const float *signal, int64_t B, int64_t N, const float *d
             if (mu) {   // the lazy screen's floor: where this run's maxima are expected to end (mppersist.inc)
                 // (rank K + K/16 + 1: now and then one event leaves two peaks; radius 1 + ceil(max(0, L - 512) / 256) blocks)
                 const int tuned = persist_radius.load(std::memory_order_relaxed);
-                const int radius = tuned > 0 ? tuned : (int)(1 + std::max<int64_t>(0, (L - 512 + 255) / 256));
+                const int radius = tuned > 0 ? tuned : tuned < 0 ? 0 : (int)(1 + std::max<int64_t>(0, (L - 512 + 255) / 256));
                 if (g.NBLK <= FLOOR_WAVE_MAXBLK)
                     hipLaunchKernelGGL(persist_floor_wave_kernel, dim3((unsigned)B), dim3(64), 0, st, (const unsigned *)w.bsum, g.NBLK,
                                        K + K / 16 + 1, radius, lbfloor);

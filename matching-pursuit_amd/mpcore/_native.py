@@ -222,9 +222,11 @@ def default_path(n_atom_samples):
 
 
 def encode_checked(signal, dict_unit, n_steps, flags=0, want_residual=True):
-    """encode() on the default path, plus the one thing the asynchronous call cannot do itself: if a
-    segment's FFT screen overflowed (marked in-band with gain = NaN, see include/mpcore.h) that segment is
-    re-encoded on the incremental path.  Costs one host synchronisation."""
+    """encode() on the default path, plus the one thing the asynchronous call cannot do itself: segments whose FFT
+    screen overflowed (marked in-band with gain = NaN, see include/mpcore.h) are encoded again -- first on the same
+    schedule without the lazy screen (its stale bounds add contenders on signals whose maxima collapse within the run:
+    such marks go away at the FFT schedule's speed), then, if still marked (near-ties: duplicated atoms, periodic
+    signals), on the incremental path.  Costs one host synchronisation."""
     path = default_path(dict_unit.shape[1])
     atom, lag, gain, residual = encode(signal, dict_unit, n_steps, path=path, flags=flags,
                                        want_residual=want_residual)
@@ -232,11 +234,18 @@ def encode_checked(signal, dict_unit, n_steps, flags=0, want_residual=True):
         bad = torch.isnan(gain).any(dim=1)
         if bool(bad.any()):
             idx = torch.nonzero(bad).flatten()
-            a2, l2, g2, r2 = encode(signal[idx], dict_unit, n_steps, path=MP_PATH_INCREMENTAL, flags=flags,
-                                    want_residual=want_residual)
-            atom[idx], lag[idx], gain[idx] = a2, l2, g2
-            if want_residual:
-                residual[idx] = r2
+            for retry_path, kw in ((MP_PATH_FFT, {"coherence": False}), (MP_PATH_INCREMENTAL, {})):
+                if retry_path == MP_PATH_FFT and not (last_schedule() == -1 and persist_stats()["skipped"] > 0):
+                    continue                               # (the lazy screen was not in play: the same run again)
+                a2, l2, g2, r2 = encode(signal[idx], dict_unit, n_steps, path=retry_path, flags=flags,
+                                        want_residual=want_residual, **kw)
+                atom[idx], lag[idx], gain[idx] = a2, l2, g2
+                if want_residual:
+                    residual[idx] = r2
+                still = torch.isnan(g2).any(dim=1)
+                if not bool(still.any()):
+                    break
+                idx = idx[still]
     return atom, lag, gain, residual
 
 

@@ -282,6 +282,34 @@ def test_approximate_correlation_matches_reference(golden_dir):
         assert sorted((e[0], e[1], int(e[2])) for e in ev2) == sorted((e[0], e[1], int(e[2])) for e in events)
 
 
+def test_encode_checked_retries_lazy_marks_without_the_lazy_screen():
+    """encode_checked: segments the lazy screen's stale bounds pushed over the contender limit (margin 1.0 provokes it on
+    a signal with fewer events than steps) come back from the same schedule without the coherence table -- identical to
+    the plain run, nothing left marked."""
+    from mpcore import _native as nat, synth
+    A, L, N, B, K = 107, 700, 8086, 40, 34
+    d = synth.make_dictionary(A, L, seed=115)
+    du = nat.unit_norm(torch.from_numpy(d).to(DEV))
+    x = torch.from_numpy(synth.make_segments(B, N, d, n_events=25, seed=215)).to(DEV)
+    ref = nat.encode(x, du, K, path=nat.MP_PATH_FFT, flags=nat.MP_FLAG_NO_OVERLAP, coherence=False)
+    assert not torch.isnan(ref[2]).any()
+    try:
+        nat.tune(nat.MP_TUNE_LAZY_MARGIN, 1.0)
+        nat.tune(nat.MP_TUNE_LAZY_REUSE, 4)
+        nat.tune(nat.MP_TUNE_LAZY_RADIUS, -1)     # (every strong block of an event counts as a peak: the floor comes out too high)
+        raw = nat.encode(x, du, K, path=nat.MP_PATH_FFT, coherence=nat.coherence_table(du))
+        assert int(torch.isnan(raw[2]).any(dim=1).sum()) > 0      # (the situation this test is about)
+        nat._coherence_cache.clear()
+        for rep in range(2):                       # the second sighting of `du` brings the table
+            out = nat.encode_checked(x, du, K)
+            assert not torch.isnan(out[2]).any()
+            assert all(torch.equal(p, q) for p, q in zip(out, ref)), rep
+    finally:
+        nat.tune(nat.MP_TUNE_LAZY_MARGIN, 0.7)
+        nat.tune(nat.MP_TUNE_LAZY_REUSE, 0)
+        nat.tune(nat.MP_TUNE_LAZY_RADIUS, 0)
+
+
 def test_multichannel_behaviour_matches_reference(golden_dir):
     """More than one channel: the reference's sparse_code raises a RuntimeError at its first scatter (:49-52) -- so
     does this one, up front; the decoder's multi-channel branch (the i-th event of a segment goes to channel i,
