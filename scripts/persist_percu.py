@@ -36,7 +36,7 @@ if mode == "percu":     # workgroups per CU against the batch size, and the laun
 else:                   # one batch size: total workgroups x select workers
     B = int(mode)
     x = torch.from_numpy(synth.make_segments(B, N, d, n_events=192, seed=1002)).cuda()
-    for nsel in (32, 48, 64):
+    for nsel in (32, 48, 64, 96, 128):
         nat.tune(nat.MP_TUNE_PERSIST_SELECTS, nsel)
         row = []
         for workers in (512, 576, 640, 704, 768):
