@@ -1954,7 +1954,8 @@ static int encode_impl(const float *signal, int64_t B, int64_t N, const float *d
     // opt-in elsewhere (MP_FLAG_OVERLAP).  Only on streams seen to run side by side (stream_pool).
     // The persistent schedule (mppersist.inc): step 0 as separate kernels (full-pass screen, quarter select), then
     // steps 1 .. K-1 of the whole batch in one launch of resident workgroups.
-    // Default for MP_PATH_FFT from 24 segments up where it applies (MP_FLAG_FFT_NO_PERSISTENT, or any flag that asks for
+    // Default for MP_PATH_FFT from 24 segments up (from 8 where the dictionary has at least 8 tiles of 32 atoms) where it applies
+    // (MP_FLAG_FFT_NO_PERSISTENT, or any flag that asks for
     // a particular launch-per-step form or sub-batch count, turns it off; MP_FLAG_FFT_PERSISTENT asks for it at any size).
     // Measured, headline dictionary, eight encodes back to back (scripts/persist_percu.py; k segment-iterations/s,
     // persistent / one stream / sub-batches): 16 segments 415 / 420 / 388, 24: 577 / 519 / 520, 32: 732 / 572 / 647,
@@ -1962,7 +1963,12 @@ static int encode_impl(const float *signal, int64_t B, int64_t N, const float *d
     const int forms = MP_FLAG_NO_OVERLAP | MP_FLAG_OVERLAP | MP_FLAG_FFT_NO_QUARTER | MP_FLAG_FFT_QUARTER | MP_FLAG_FFT_FUSED |
                       MP_FLAG_FFT_UNFUSED | MP_FLAG_REFINE_MFMA | MP_FLAG_FFT_SIMPLE | MP_FLAG_FFT_NO_PERSISTENT |
                       (7 << MP_FLAG_GROUPS_SHIFT);
-    const bool persist = path == MP_PATH_FFT && ((flags & MP_FLAG_FFT_PERSISTENT_BIT) || (B >= 24 && !(flags & forms))) &&
+    // (With the select at 15 us -- its chains on the matrix core -- the one-launch form also wins for few segments where an
+    //  entry has enough tasks to spread: 512 x 512 dictionary, persistent / one stream: 8 segments 256 / 233 k, 12: 363 /
+    //  295, 16: 462 / 407, 20: 551 / 446; 256 x 1024: 212 / 198, 306 / 252, 398 / 309, 481 / 348.  Two tiles -- 64 x 300 --
+    //  lose until 20 segments: 331 / 363 at 8, 660 / 687 at 16.  scripts/small_batches.py.)
+    const bool persist_size = B >= 24 || (B >= 8 && g.NAT >= 8);
+    const bool persist = path == MP_PATH_FFT && ((flags & MP_FLAG_FFT_PERSISTENT_BIT) || (persist_size && !(flags & forms))) &&
                          !audit_on.load(std::memory_order_relaxed);  // (the audit checks screens launch by launch)
     if (persist) {
         FftGeom f;

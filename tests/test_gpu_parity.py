@@ -672,8 +672,8 @@ def test_init_streams_and_capture_in_a_thread_without_a_pool(oracle):
 
 
 def test_which_form_the_default_schedule_takes():
-    """flags = 0 on MP_PATH_FFT: the persistent form from 24 segments up where the shape allows it (here 1024-point
-    transforms), sub-batches on forked streams (from 48 segments) where it does not (512-point transforms) or when a
+    """flags = 0 on MP_PATH_FFT: the persistent form from 24 segments up (from 8 with at least eight 32-atom tiles) where the
+    shape allows it (here 1024-point transforms), sub-batches on forked streams (from 48 segments) where it does not (512-point transforms) or when a
     flag names another form, one stream below; mp_last_schedule() tells which.  All bit-identical."""
     d = synth.make_dictionary(64, 256, seed=61)
     du = nat.unit_norm(torch.from_numpy(d).to(DEV))
@@ -694,6 +694,14 @@ def test_which_form_the_default_schedule_takes():
         assert all(torch.equal(p[:, :K], q[:, :K]) for p, q in zip(out[:3], ref[:3])), K
     nat.encode(x, du, 1, path=nat.MP_PATH_FFT)        # a single step has no steps 1 .. K-1 to put in one launch
     assert nat.last_schedule() == streams
+    d3 = synth.make_dictionary(256, 256, seed=53)     # eight tiles of 32 atoms: an entry has enough tasks to spread from 8 segments
+    du3 = nat.unit_norm(torch.from_numpy(d3).to(DEV))
+    x3 = torch.from_numpy(synth.make_segments(9, 6000, d3, n_events=10, seed=54)).to(DEV)
+    ref3 = nat.encode(x3, du3, 6, path=nat.MP_PATH_FFT, flags=nat.MP_FLAG_NO_OVERLAP)
+    for n, want in ((9, -1), (8, -1), (7, 1)):
+        out = nat.encode(x3[:n], du3, 6, path=nat.MP_PATH_FFT)
+        assert nat.last_schedule() == want, (n, nat.last_schedule())
+        assert all(torch.equal(p, q[:n]) for p, q in zip(out, ref3)), n
     d2 = synth.make_dictionary(40, 96, seed=51)       # 512-point transforms: outside the persistent form
     x2 = torch.from_numpy(synth.make_segments(50, 3000, d2, n_events=10, seed=52)).to(DEV)
     nat.encode(x2, nat.unit_norm(torch.from_numpy(d2).to(DEV)), 4, path=nat.MP_PATH_FFT)
