@@ -118,6 +118,8 @@ int mp_profile_enable(int every);
                                      0 -- a block counts if it is the best within this many blocks either side; 0 (default) =
                                      by atom length, 1 + ceil(max(0, L - 512) / 256); -1 = every block counts (tests: the floor comes out too high).  Smaller = more skips, and stale contenders
                                      (overflow marks) on signals whose maxima collapse within the run                          */
+#define MP_TUNE_PERSIST_PRESCAN 14 /* persistent form: a select worker that holds an entry whose screen is still running scans the
+                                     blocks that screen does not touch -- and refines their contenders -- meanwhile (1, default; 0: off) */
 int mp_tune(int key, double value);
 int mp_profile_read(double *ms, int64_t *count);
 

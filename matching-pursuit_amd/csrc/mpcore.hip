@@ -1866,6 +1866,7 @@ int mp_tune(int key, double value) {
     if (key == MP_TUNE_LAZY_MARGIN && value > 0.0 && value <= 1.0) { persist_margin.store((float)value); return MP_OK; }
     if (key == MP_TUNE_LAZY_REUSE && value >= 0 && value <= 4) { persist_reuse.store((int)value); return MP_OK; }
     if (key == MP_TUNE_LAZY_RADIUS && value >= -1 && value <= 64) { persist_radius.store((int)value); return MP_OK; }
+    if (key == MP_TUNE_PERSIST_PRESCAN && (value == 0 || value == 1)) { persist_prescan.store((int)value); return MP_OK; }
     return fail(MP_ERR_ARG, "mp_tune: unknown key or bad value%s");
 }
 

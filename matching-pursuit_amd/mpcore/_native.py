@@ -33,6 +33,7 @@ MP_TUNE_PERSIST_SELECTS = 8
 MP_TUNE_LAZY_MARGIN = 10
 MP_TUNE_LAZY_REUSE = 12
 MP_TUNE_LAZY_RADIUS = 13
+MP_TUNE_PERSIST_PRESCAN = 14
 MP_FLAG_GROUPS_SHIFT = 20
 MP_FLAG_NO_OVERLAP = 4096
 MP_FLAG_FFT_NO_QUARTER = 8192
@@ -170,6 +171,7 @@ def persist_stats():
     out["skipped"] = int(buf[14])
     out["select_phase_us"] = {p: round(int(buf[8 + i]) / 100.0 / n, 2)
                               for i, p in enumerate(("acquire", "scan", "chains", "event_window", "transform_stores"))}
+    out["prescans"] = int(buf[15])
     return out
 
 
