@@ -724,6 +724,31 @@ def test_coherence_table_bounds_the_exact_one():
     assert nat.lib().mp_coherence_workspace_bytes(64, 40) == 0     # 512-point transforms: no lazy screen
 
 
+def test_select_workers_working_ahead_change_nothing():
+    """MP_TUNE_PERSIST_PRESCAN: a select worker scans the blocks a running screen does not touch, refines their contenders
+    and prepares the window its best key would leave while it waits for that screen -- the events, gains and residuals are
+    the same bit for bit with it on and off, with and without the lazy screen, and it does happen."""
+    try:
+        for A, L, N, B, K in ((256, 256, 9000, 32, 24), (512, 512, 32768, 24, 20), (100, 1000, 20000, 40, 12)):
+            d = synth.make_dictionary(A, L, seed=A + 1)
+            du = nat.unit_norm(torch.from_numpy(d).to(DEV))
+            x = torch.from_numpy(synth.make_segments(B, N, d, n_events=3 * K, seed=B + 1)).to(DEV)
+            ref = nat.encode(x, du, K, path=nat.MP_PATH_FFT, flags=nat.MP_FLAG_NO_OVERLAP, coherence=False)
+            mu = nat.coherence_table(du)
+            for co in (False, mu):
+                for on in (0, 1):
+                    nat.tune(nat.MP_TUNE_PERSIST_PRESCAN, on)
+                    nat.persist_stats()
+                    out = nat.encode(x, du, K, path=nat.MP_PATH_FFT, flags=nat.MP_FLAG_FFT_PERSISTENT, coherence=co)
+                    torch.cuda.synchronize()
+                    st = nat.persist_stats()
+                    assert nat.last_schedule() == -1 and st["error"] == 0
+                    assert all(torch.equal(p, q) for p, q in zip(out, ref)), (A, L, on, co is not False)
+                    assert (st["prescans"] > st["selects"] // 4) if on else st["prescans"] == 0, (on, st["prescans"], st["selects"])
+    finally:
+        nat.tune(nat.MP_TUNE_PERSIST_PRESCAN, 1)
+
+
 def test_lazy_screen_leaves_no_stale_contenders_when_the_maxima_collapse():
     """Fewer planted events than steps: once they are gone the running maximum falls to the noise floor.  Cells the lazy
     screen left with widened bounds during the strong phase must not turn into contenders then (they overflowed every
