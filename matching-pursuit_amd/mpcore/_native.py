@@ -359,9 +359,9 @@ def encode(signal, dict_unit, n_steps, path=MP_PATH_INCREMENTAL, flags=0, want_r
         if dict_unit.data_ptr() == dict_owner.data_ptr():   # (a converted copy is a temporary: nothing to remember)
             coherence = cached_coherence(dict_unit, dict_owner)   # (None until the same dictionary tensor comes a second time)
         # a batch large enough for the table to pay for itself within this one call gets it at once, new dictionary or not:
-        # the table is A * A / 2 transforms, the launch it trims B (K - 1) A / 2, of which a quarter go when the launch
-        # is work-bound (from ~96 segments; 128 x 64 steps at 512 atoms: 7.3 -> 5.5 + 0.45 ms)
-        if coherence is None and B >= 96 and B * (K - 1) >= 8 * A and not torch.cuda.is_current_stream_capturing() and \
+        # the table is A * A / 2 transforms, the launch it trims B (K - 1) A / 2, of which a third go (512 atoms, 64 steps:
+        # 64 segments 3.75 -> 2.93 + 0.45 ms, 128 segments 7.3 -> 5.4 + 0.45 ms; 48 segments 3.21 -> 2.82 + 0.45: not yet)
+        if coherence is None and B >= 64 and B * (K - 1) >= 6 * A and not torch.cuda.is_current_stream_capturing() and \
                 lib().mp_coherence_workspace_bytes(A, L):
             coherence = coherence_table(dict_unit)
     nbytes = workspace_bytes(B, N, A, L, K, path)
