@@ -11,11 +11,11 @@ collective on the data path, weak scaling; rank 0 prints ONE JSON line.
 
 value = segment-iterations/s over all ranks, inputs resident in HBM, timed between
 barrier+synchronize pairs, max over ranks, on the library's default schedule for this shape (flags = 0:
-MP_PATH_FFT, FFT screen + exact refinement, events bit-identical to the direct paths, re-checked every run; from 48
-segments up the persistent form -- step 0 as separate kernels, steps 1 .. K-1 of the whole batch in ONE launch,
-csrc/mppersist.inc -- and, from the second encode against the same dictionary tensor, its lazy screen: the coherence
-table it needs, 0.45 ms, is computed in that second encode -- the second warm-up step by default, the first timed
-step with --warmup 1).  `variants` carries the launch-per-step forms of the same schedule (one stream: the form whose
+MP_PATH_FFT, FFT screen + exact refinement, events bit-identical to the direct paths, re-checked every run; the
+persistent form -- step 0 as separate kernels, steps 1 .. K-1 of the whole batch in ONE launch, csrc/mppersist.inc -- with
+its lazy screen: the coherence table it needs, 0.45 ms, is computed by the first encode of a batch this size (from 64
+segments one call pays for it: mpcore/_native.py::encode), i.e. in the first warm-up step; with --warmup 0 inside the
+timed region).  `variants` carries the launch-per-step forms of the same schedule (one stream: the form whose
 per-step screen kernel has its own roofline; four sub-batches on forked streams), the default's replay from a
 captured hipGraph (mpcore.EncodePlan) and the two direct-correlation (MFMA) schedules with their own rooflines.
 `roofline` is for the dominant kernel from HIP events recorded inside the timed region on the launch stream (the
@@ -264,9 +264,10 @@ def roofline_persistent(prof, n_segments, steps):
     out["lazy_screen"] = {
         "transforms_without_it": all_transforms, "transforms_run": transforms,
         "tasks_answered_without_a_transform": pst["skipped"],
-        "note": "the dictionary tensor's coherence table (mp_coherence_f32, ~0.45 ms) is computed at the second encode against "
-                "the same tensor (mpcore/_native.py::cached_coherence): " +
-                ("during warm-up" if WARMUP_STEPS >= 2 else "inside the timed region, in its first step"),
+        "note": "the dictionary tensor's coherence table (mp_coherence_f32, ~0.45 ms) is computed by the first encode of a batch this "
+                "size (mpcore/_native.py::encode: from 64 segments one call pays for it; smaller batches get it at the second "
+                "encode against the same tensor): " +
+                ("during warm-up" if WARMUP_STEPS >= 1 else "inside the timed region, in its first step"),
     }
     out["inside_the_launch"] = {
         "screen_task_us": round(pst["task_ticks"] / max(pst["tasks"], 1) / 100.0, 2), "tasks": pst["tasks"],
