@@ -69,7 +69,7 @@ extern "C" {
 #define MP_FLAG_FFT_QUARTER 16384   /* MP_PATH_FFT: the quarter-cell select also when the batch stays on one stream */
 #define MP_FLAG_FFT_PERSISTENT 65536 /* MP_PATH_FFT: steps 1 .. K-1 of the whole batch in ONE launch of resident workgroups that
                                         pull screen tasks from a queue while select workers serve the segments whose screens
-                                        are complete (csrc/mppersist.inc).  Default from 24 segments up (from 8 where the dictionary has at least eight 32-atom tiles) where it applies
+                                        are complete (csrc/mppersist.inc).  Default at every batch size where it applies
                                         (no split transforms, <= 16384 cells per segment, 1024 <= M <= 4096, <= 2 GiB of window records); this flag
                                         asks for it at any batch size; shapes it does not cover use the other forms   */
 #define MP_FLAG_FFT_NO_PERSISTENT 131072 /* MP_PATH_FFT: launch-per-step kernels (sub-batches on forked streams from 48 segments) */

@@ -1955,7 +1955,7 @@ static int encode_impl(const float *signal, int64_t B, int64_t N, const float *d
     // opt-in elsewhere (MP_FLAG_OVERLAP).  Only on streams seen to run side by side (stream_pool).
     // The persistent schedule (mppersist.inc): step 0 as separate kernels (full-pass screen, quarter select), then
     // steps 1 .. K-1 of the whole batch in one launch of resident workgroups.
-    // Default for MP_PATH_FFT from 24 segments up (from 8 where the dictionary has at least 8 tiles of 32 atoms) where it applies
+    // Default for MP_PATH_FFT at every batch size where it applies
     // (MP_FLAG_FFT_NO_PERSISTENT, or any flag that asks for
     // a particular launch-per-step form or sub-batch count, turns it off; MP_FLAG_FFT_PERSISTENT asks for it at any size).
     // Measured, headline dictionary, eight encodes back to back (scripts/persist_percu.py; k segment-iterations/s,
@@ -1968,7 +1968,11 @@ static int encode_impl(const float *signal, int64_t B, int64_t N, const float *d
     //  entry has enough tasks to spread: 512 x 512 dictionary, persistent / one stream: 8 segments 256 / 233 k, 12: 363 /
     //  295, 16: 462 / 407, 20: 551 / 446; 256 x 1024: 212 / 198, 306 / 252, 398 / 309, 481 / 348.  Two tiles -- 64 x 300 --
     //  lose until 20 segments: 331 / 363 at 8, 660 / 687 at 16.  scripts/small_batches.py.)
-    const bool persist_size = B >= 24 || (B >= 8 && g.NAT >= 8);
+    // (... and with the select workers working ahead of their screens -- a select is 6 us then -- it wins at every batch size, one
+    //  segment included: 512 x 512, persistent / one stream 48 / 41 k at 1 segment, 94 / 75 at 2, 181 / 137 at 4, 250 / 187
+    //  at 6; 256 x 1024: 42 / 33, 78 / 62, 145 / 113, 207 / 159; 64 x 300: 54 / 48, 105 / 92, 204 / 186, 302 / 272, 600 /
+    //  516 at 12.)
+    const bool persist_size = true;
     const bool persist = path == MP_PATH_FFT && ((flags & MP_FLAG_FFT_PERSISTENT_BIT) || (persist_size && !(flags & forms))) &&
                          !audit_on.load(std::memory_order_relaxed);  // (the audit checks screens launch by launch)
     if (persist) {

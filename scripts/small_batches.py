@@ -11,7 +11,7 @@ def rate(B, x, **kw):
     f(); torch.cuda.synchronize(); t0 = time.perf_counter()
     for _ in range(8): f()
     torch.cuda.synchronize(); return B * K * 8 / (time.perf_counter() - t0) / 1e3
-for B in (4, 6, 8, 12, 16, 20):
+for B in (1, 2, 3, 4, 6, 8, 12):
     x = torch.from_numpy(synth.make_segments(B, N, d, n_events=192, seed=1002)).cuda()
     row = [f"default {rate(B, x, coherence=False):6.0f} k (schedule {nat.last_schedule()})"]
     row.append(f"persistent {rate(B, x, flags=nat.MP_FLAG_FFT_PERSISTENT, coherence=False):6.0f} k")

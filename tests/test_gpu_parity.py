@@ -672,8 +672,8 @@ def test_init_streams_and_capture_in_a_thread_without_a_pool(oracle):
 
 
 def test_which_form_the_default_schedule_takes():
-    """flags = 0 on MP_PATH_FFT: the persistent form from 24 segments up (from 8 with at least eight 32-atom tiles) where the
-    shape allows it (here 1024-point transforms), sub-batches on forked streams (from 48 segments) where it does not (512-point transforms) or when a
+    """flags = 0 on MP_PATH_FFT: the persistent form at every batch size where the shape allows it (here 1024-point
+    transforms), sub-batches on forked streams (from 48 segments) where it does not (512-point transforms) or when a
     flag names another form, one stream below; mp_last_schedule() tells which.  All bit-identical."""
     d = synth.make_dictionary(64, 256, seed=61)
     du = nat.unit_norm(torch.from_numpy(d).to(DEV))
@@ -681,7 +681,8 @@ def test_which_form_the_default_schedule_takes():
     streams = min(4, nat.init_streams())
     ref = nat.encode(x, du, 7, path=nat.MP_PATH_FFT, flags=nat.MP_FLAG_NO_OVERLAP)
     assert nat.last_schedule() == 1
-    for flags, n, want in ((0, 56, -1), (0, 24, -1), (0, 23, 1), (nat.MP_FLAG_FFT_PERSISTENT, 5, -1), (nat.MP_FLAG_FFT_NO_PERSISTENT, 56, streams),
+    for flags, n, want in ((0, 56, -1), (0, 24, -1), (0, 23, -1), (0, 2, -1), (0, 1, -1), (nat.MP_FLAG_FFT_PERSISTENT, 5, -1), (nat.MP_FLAG_FFT_NO_PERSISTENT, 56, streams),
+                           (nat.MP_FLAG_FFT_NO_PERSISTENT, 23, 1),
                            (nat.flag_groups(2), 56, min(2, streams)), (nat.MP_FLAG_FFT_FUSED, 56, streams)):
         out = nat.encode(x[:n], du, 7, path=nat.MP_PATH_FFT, flags=flags)
         assert nat.last_schedule() == want, (flags, n, nat.last_schedule())
@@ -694,11 +695,11 @@ def test_which_form_the_default_schedule_takes():
         assert all(torch.equal(p[:, :K], q[:, :K]) for p, q in zip(out[:3], ref[:3])), K
     nat.encode(x, du, 1, path=nat.MP_PATH_FFT)        # a single step has no steps 1 .. K-1 to put in one launch
     assert nat.last_schedule() == streams
-    d3 = synth.make_dictionary(256, 256, seed=53)     # eight tiles of 32 atoms: an entry has enough tasks to spread from 8 segments
+    d3 = synth.make_dictionary(256, 256, seed=53)     # eight tiles of 32 atoms
     du3 = nat.unit_norm(torch.from_numpy(d3).to(DEV))
     x3 = torch.from_numpy(synth.make_segments(9, 6000, d3, n_events=10, seed=54)).to(DEV)
     ref3 = nat.encode(x3, du3, 6, path=nat.MP_PATH_FFT, flags=nat.MP_FLAG_NO_OVERLAP)
-    for n, want in ((9, -1), (8, -1), (7, 1)):
+    for n, want in ((9, -1), (8, -1), (7, -1), (1, -1)):
         out = nat.encode(x3[:n], du3, 6, path=nat.MP_PATH_FFT)
         assert nat.last_schedule() == want, (n, nat.last_schedule())
         assert all(torch.equal(p, q[:n]) for p, q in zip(out, ref3)), n
