@@ -120,6 +120,8 @@ int mp_profile_enable(int every);
                                      (overflow marks) on signals whose maxima collapse within the run                          */
 #define MP_TUNE_PERSIST_PRESCAN 14 /* persistent form: a select worker that holds an entry whose screen is still running scans the
                                      blocks that screen does not touch -- and refines their contenders -- meanwhile (1, default; 0: off) */
+#define MP_TUNE_CLEAR_MEMSET 15    /* debug: 1 = the encode's clears are hipMemsetAsync calls instead of one kernel launch (what a
+                                     stream capture makes of memset nodes: scripts/graph_memset_repro.py); 0 (default) */
 int mp_tune(int key, double value);
 int mp_profile_read(double *ms, int64_t *count);
 

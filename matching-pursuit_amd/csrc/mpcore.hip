@@ -1079,6 +1079,7 @@ __global__ __launch_bounds__(1024) void dictionary_update_level_kernel(
 // Workspace carving (all offsets multiples of 256 bytes)
 // ------------------------------------------------------------------------------------------------
 #include "mpfft.inc"
+#include "mplevels.inc"
 
 // bytes of the persistent form's control block + ticket lines + queue (mppersist.inc: PersistCtl <= 256, 512 lines of 64,
 // B (K - 1) + 2 entries of 128); carve() reserves them, fft_setup clears them
@@ -1411,7 +1412,12 @@ __global__ void clear_words_kernel(ClearList c) {
         for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) p[i] = 0u;
     }
 }
+std::atomic<int> clear_with_memset{0};   // debug hook (MP_TUNE_CLEAR_MEMSET): hipMemsetAsync per range, as round 2 first had it
 int clear_async(const ClearList &c, hipStream_t st) {
+    if (clear_with_memset.load(std::memory_order_relaxed)) {   // (scripts/graph_memset_repro.py: what a capture makes of these)
+        for (int r = 0; r < c.count; ++r) HIP_TRY(hipMemsetAsync(c.p[r], 0, c.n[r] * 4, st));
+        return MP_OK;
+    }
     size_t most = 0;
     for (int r = 0; r < c.count; ++r) most = std::max(most, c.n[r]);
     if (!most) return MP_OK;
@@ -1867,6 +1873,7 @@ int mp_tune(int key, double value) {
     if (key == MP_TUNE_LAZY_REUSE && value >= 0 && value <= 4) { persist_reuse.store((int)value); return MP_OK; }
     if (key == MP_TUNE_LAZY_RADIUS && value >= -1 && value <= 64) { persist_radius.store((int)value); return MP_OK; }
     if (key == MP_TUNE_PERSIST_PRESCAN && (value == 0 || value == 1)) { persist_prescan.store((int)value); return MP_OK; }
+    if (key == MP_TUNE_CLEAR_MEMSET && (value == 0 || value == 1)) { clear_with_memset.store((int)value); return MP_OK; }
     return fail(MP_ERR_ARG, "mp_tune: unknown key or bad value%s");
 }
 
@@ -2288,43 +2295,11 @@ int mp_dictionary_update_f32(float *residual, float *sparse_zeroed, int64_t B, i
 
 int mp_dictionary_levels_host(const int64_t *offsets, int64_t n_groups, const int64_t *ev_batch, const int64_t *ev_lag,
                               int64_t n_events, int64_t L, int32_t *level, int32_t *overlap, int64_t *n_levels) {
-    if (!offsets || !ev_batch || !ev_lag || !level || !overlap || !n_levels || n_groups < 0 || n_events < 0 || L <= 0)
-        return fail(MP_ERR_ARG, "mp_dictionary_levels_host: bad arguments%s");
-    if (n_groups && offsets[n_groups] != n_events) return fail(MP_ERR_ARG, "mp_dictionary_levels_host: offsets do not cover the events%s");
-    std::vector<int32_t> group((size_t)n_events);
-    for (int64_t g = 0; g < n_groups; ++g) {
-        level[g] = 0;
-        overlap[g] = 0;
-        for (int64_t e = offsets[g]; e < offsets[g + 1]; ++e) group[(size_t)e] = (int32_t)g;
+    switch (mplevels::dictionary_levels(offsets, n_groups, ev_batch, ev_lag, n_events, L, level, overlap, n_levels)) {   // (mplevels.inc: plain host C++)
+        case 0: return MP_OK;
+        case 2: return fail(MP_ERR_ARG, "mp_dictionary_levels_host: offsets do not cover the events%s");
+        default: return fail(MP_ERR_ARG, "mp_dictionary_levels_host: bad arguments%s");
     }
-    std::vector<int64_t> idx((size_t)n_events);
-    for (int64_t e = 0; e < n_events; ++e) idx[(size_t)e] = e;
-    std::sort(idx.begin(), idx.end(), [&](int64_t a, int64_t b) {
-        return ev_batch[a] != ev_batch[b] ? ev_batch[a] < ev_batch[b] : (ev_lag[a] != ev_lag[b] ? ev_lag[a] < ev_lag[b] : a < b);
-    });
-    // pairs of events that share a sample: same segment, lags less than L apart
-    std::vector<std::pair<int32_t, int32_t>> edges;  // (later group, earlier group)
-    for (int64_t i = 0; i < n_events; ++i) {
-        const int64_t a = idx[(size_t)i];
-        for (int64_t j = i + 1; j < n_events; ++j) {
-            const int64_t b = idx[(size_t)j];
-            if (ev_batch[b] != ev_batch[a] || ev_lag[b] - ev_lag[a] >= L) break;
-            const int32_t ga = group[(size_t)a], gb = group[(size_t)b];
-            if (ga == gb) overlap[ga] = 1;
-            else edges.emplace_back(ga > gb ? ga : gb, ga > gb ? gb : ga);
-        }
-    }
-    std::sort(edges.begin(), edges.end());
-    int32_t top = -1;
-    size_t q = 0;
-    for (int64_t g = 0; g < n_groups; ++g) {  // ascending: every earlier group's level is final
-        int32_t lv = 0;
-        for (; q < edges.size() && edges[q].first == g; ++q) lv = std::max(lv, level[edges[q].second] + 1);
-        level[g] = lv;
-        top = std::max(top, lv);
-    }
-    *n_levels = (int64_t)top + 1;
-    return MP_OK;
 }
 
 int mp_dictionary_update_levels_f32(float *residual, float *sparse_zeroed, int64_t B, int64_t N, float *dict_work,

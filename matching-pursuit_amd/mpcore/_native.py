@@ -34,6 +34,7 @@ MP_TUNE_LAZY_MARGIN = 10
 MP_TUNE_LAZY_REUSE = 12
 MP_TUNE_LAZY_RADIUS = 13
 MP_TUNE_PERSIST_PRESCAN = 14
+MP_TUNE_CLEAR_MEMSET = 15
 MP_FLAG_GROUPS_SHIFT = 20
 MP_FLAG_NO_OVERLAP = 4096
 MP_FLAG_FFT_NO_QUARTER = 8192
@@ -232,12 +233,13 @@ def encode_checked(signal, dict_unit, n_steps, flags=0, want_residual=True):
     path = default_path(dict_unit.shape[1])
     atom, lag, gain, residual = encode(signal, dict_unit, n_steps, path=path, flags=flags,
                                        want_residual=want_residual)
+    was_lazy = bool(getattr(_tls, "lazy", False))   # (this thread's call, not the process-wide statistics of the last launch)
     if path == MP_PATH_FFT and gain.numel():
         bad = torch.isnan(gain).any(dim=1)
         if bool(bad.any()):
             idx = torch.nonzero(bad).flatten()
             for retry_path, kw in ((MP_PATH_FFT, {"coherence": False}), (MP_PATH_INCREMENTAL, {})):
-                if retry_path == MP_PATH_FFT and not (last_schedule() == -1 and persist_stats()["skipped"] > 0):
+                if retry_path == MP_PATH_FFT and not was_lazy:
                     continue                               # (the lazy screen was not in play: the same run again)
                 a2, l2, g2, r2 = encode(signal[idx], dict_unit, n_steps, path=retry_path, flags=flags,
                                         want_residual=want_residual, **kw)
@@ -289,38 +291,111 @@ def coherence_table(dict_unit, chunk=128, exact=False):
     return out + float(L) * 5.9604645e-8 * float(dict_unit.norm(dim=-1).max()) ** 2
 
 
-_coherence_cache = {}   # (data_ptr, version, shape, device) -> weakref(tensor) after its first sighting, (table, tensor) after
+class _RememberedDictionary:
+    """One remembered dictionary per (shape, device, stream): a private COPY of the normalised dictionary, the coherence
+    table computed from that copy, and the pinned flag a call's device-side comparison lands in (read, without waiting
+    for it, by a later call)."""
+    __slots__ = ("copy", "table", "flag", "event", "pending", "volatile")
+
+    def __init__(self, dict_unit):
+        self.copy = dict_unit.clone()
+        self.table = None
+        self.flag = torch.zeros(1, dtype=torch.bool).pin_memory()
+        self.event = torch.cuda.Event()
+        self.pending = False
+        self.volatile = False      # the dictionary was seen to change between calls: nothing is kept until it stops
 
 
-def cached_coherence(dict_unit, owner=None):
-    """The coherence table of a dictionary TENSOR that has been encoded against before, else None.  The table is computed
-    (mp_coherence_f32, ~0.45 ms at 512 x 512) at the second sighting of the same live tensor object with the same storage
-    and version counter -- so a dictionary that is re-normalised or updated every call (a training loop; the temporaries
-    of sparse_code) never pays for it, and one that is encoded against again and again (a fixed dictionary: the streaming
-    encoder, an EncodePlan, bench.py) pays once.  The cache holds the tensor, so its storage cannot be handed to another
-    one; torch's in-place operations bump the version counter (do not write into a cached dictionary behind torch's
-    back).  At most 8 dictionaries are remembered; shapes the lazy screen does not cover return None."""
-    import weakref
-    owner = dict_unit if owner is None else owner   # the caller's tensor object (encode() passes the one it was given:
-    A, L = dict_unit.shape                           # its own fp32 / contiguous view is a new object every call)
-    if lib().mp_coherence_workspace_bytes(A, L) == 0:
+_coherence_cache = {}   # (shape, device, stream) -> _RememberedDictionary
+_coherence_lock = __import__("threading").Lock()
+COHERENCE_CACHE_ENTRIES = 8
+
+
+def clear_caches():
+    """Forget every remembered dictionary and coherence table (device memory: a copy of the dictionary and an
+    [A, A / 32] table per entry, at most COHERENCE_CACHE_ENTRIES entries)."""
+    with _coherence_lock:
+        _coherence_cache.clear()
+
+
+def validated_table(dict_unit, copy, table):
+    """`table` where `dict_unit` equals `copy` (the dictionary the table was computed from) in every element, +inf
+    everywhere otherwise -- decided ON THE DEVICE, in stream order, no host synchronisation: with an infinite coherence
+    the lazy screen's widened bound never stays below anything, so no tile is ever skipped and the encode is the plain
+    one (mppersist.inc: `val + ev + |g| mu < LB_clean` is false; for |g| = 0 the product is NaN and compares false
+    too).  -> (table to hand to mp_encode_lazy_f32, the 0-d bool tensor of the comparison)."""
+    same = (dict_unit == copy).all()
+    return torch.where(same, table, torch.full_like(table, float("inf"))), same
+
+
+def cached_coherence(dict_unit, build_now=False):
+    """The coherence table for the lazy screen if THIS dictionary -- by content -- has been encoded against before (or,
+    with build_now, in any case), else None.
+
+    Nothing here trusts object identity, storage pointers or torch's version counter (writes through `.data`, which is how
+    the reference's experiments update their dictionaries -- experiments/archive/e_2023_7_20/experiment.py:269-283 --
+    do not bump it).  Per (shape, device, stream) one dictionary is remembered as a private copy, with the table
+    computed from that copy.  A remembered table is only ever handed out through validated_table(): the call's dictionary
+    is compared with the copy on the device and the kernel gets the table where they are equal and +inf (no tile
+    skipped: the plain encode) where they are not -- a stale table cannot reach a decision.  The comparison's result also
+    lands in a pinned flag which a LATER call reads once its event has completed (no waiting):
+      * equal: a dictionary seen unchanged gets its table built from the copy (mp_coherence_f32, ~0.45 ms at 512 x 512)
+        -- the lazy screen from the third encode against a fixed dictionary;
+      * different: the entry turns `volatile` -- the copy follows the dictionary call by call and no table is kept --
+        until a comparison comes back equal again.  A dictionary that changes every call never pays for a table.
+    build_now (batches large enough for one call to pay for the table): where no trusted table exists the table is
+    computed from `dict_unit` itself -- valid by construction -- and remembered with it.
+    Returns None inside a stream capture (an EncodePlan owns its table) and for shapes the lazy screen does not cover."""
+    A, L = dict_unit.shape
+    if torch.cuda.is_current_stream_capturing() or lib().mp_coherence_workspace_bytes(A, L) == 0:
         return None
-    key = (dict_unit.data_ptr(), owner._version, tuple(dict_unit.shape), str(dict_unit.device))
-    ent = _coherence_cache.get(key)
-    if isinstance(ent, tuple):
-        return ent[0]
-    if torch.cuda.is_current_stream_capturing():
-        return None   # (never build the table inside a capture: it would live in the graph's private pool)
-    if ent is not None and ent() is owner:
-        _coherence_cache[key] = (coherence_table(dict_unit), owner)
-        return _coherence_cache[key][0]
-    if len(_coherence_cache) >= 8:
-        _coherence_cache.pop(next(iter(_coherence_cache)))
-    _coherence_cache[key] = weakref.ref(owner)
-    return None
+    dev = dict_unit.device
+    stream = torch.cuda.current_stream(dev)
+    key = (A, L, str(dev), stream.cuda_stream)
+    with _coherence_lock:
+        ent = _coherence_cache.get(key)
+        if ent is None:
+            while len(_coherence_cache) >= COHERENCE_CACHE_ENTRIES:
+                _coherence_cache.pop(next(iter(_coherence_cache)))
+            ent = _coherence_cache[key] = _RememberedDictionary(dict_unit)
+            if build_now:
+                ent.table = coherence_table(ent.copy)
+            return ent.table                                   # (computed from this very dictionary: nothing to validate)
+        news = None
+        if ent.pending and ent.event.query():
+            ent.pending = False
+            news = bool(ent.flag[0])
+            if news:
+                ent.volatile = False
+            else:
+                ent.volatile, ent.table = True, None
+        trusted = ent.table is not None and not ent.volatile
+        if trusted:
+            table, same = validated_table(dict_unit, ent.copy, ent.table)
+        else:
+            table, same = None, (dict_unit == ent.copy).all()
+        if not ent.pending:
+            ent.flag.copy_(same.view(1), non_blocking=True)
+            ent.event.record(stream)
+            ent.pending = True
+        if trusted:
+            return table
+        if build_now:
+            ent.copy.copy_(dict_unit)                          # (after the comparison, in stream order)
+            table = coherence_table(ent.copy)
+            if not ent.volatile:
+                ent.table = table
+            return table
+        if news and not ent.volatile:                          # seen unchanged: worth a table
+            ent.table = coherence_table(ent.copy)
+            return validated_table(dict_unit, ent.copy, ent.table)[0]
+        if ent.volatile:
+            ent.copy.copy_(dict_unit)
+        return None
 
 
 LAZY_MIN_BATCH = 24   # (the persistent form's threshold: below it the table would not be used)
+_tls = __import__("threading").local()   # .lazy: did this thread's last encode() hand the kernel a coherence table?
 
 
 def encode(signal, dict_unit, n_steps, path=MP_PATH_INCREMENTAL, flags=0, want_residual=True, conv_model=False,
@@ -329,10 +404,10 @@ def encode(signal, dict_unit, n_steps, path=MP_PATH_INCREMENTAL, flags=0, want_r
     gain[B,K] f32, residual[B,N] f32 | None), all on signal.device, asynchronous.
     conv_model=True: mp_encode_conv_f32 (the analysis loop of mp.py's model; `dict_unit` = raw atoms).
     coherence: the dictionary's coherence_table() -> mp_encode_lazy_f32 (MP_PATH_FFT's persistent form skips the
-    transforms of tiles an event cannot have lifted into contention; same events).  None: cached_coherence() decides
-    (a dictionary tensor seen before gets its table); False: never."""
+    transforms of tiles an event cannot have lifted into contention; same events).  A table passed explicitly must belong
+    to `dict_unit` as it is NOW (a stale one skips tiles that hold the maximum -- wrong events, no mark).  None:
+    cached_coherence() decides (a dictionary seen before, compared by content on the device, gets its table); False: never."""
     signal = _f32(signal)
-    dict_owner = dict_unit
     dict_unit = _f32(dict_unit)
     _require_cuda(signal, dict_unit)
     B, N = signal.shape
@@ -343,27 +418,27 @@ def encode(signal, dict_unit, n_steps, path=MP_PATH_INCREMENTAL, flags=0, want_r
     lag = torch.empty((B, K), dtype=torch.int64, device=dev)
     gain = torch.empty((B, K), dtype=torch.float32, device=dev)
     residual = torch.empty((B, N), dtype=torch.float32, device=dev) if want_residual else None
+    _tls.lazy = False
     if B == 0:
         return atom, lag, gain, residual
     if path == MP_PATH_FFT and B > FFT_MAX_BATCH:  # one grid dimension of the screen is the batch: chunk it
+        any_lazy = False
         for b0 in range(0, B, FFT_MAX_BATCH):
             sl = slice(b0, min(b0 + FFT_MAX_BATCH, B))
             a, l, g, r = encode(signal[sl], dict_unit, K, path=path, flags=flags, want_residual=want_residual,
                                 conv_model=conv_model, coherence=coherence)
             atom[sl], lag[sl], gain[sl] = a, l, g
+            any_lazy = any_lazy or _tls.lazy
             if want_residual:
                 residual[sl] = r
+        _tls.lazy = any_lazy
         return atom, lag, gain, residual
     if coherence is None and path == MP_PATH_FFT and not conv_model and B >= LAZY_MIN_BATCH and K >= 8 and \
             not (int(flags) & ~MP_FLAG_FFT_PERSISTENT):
-        if dict_unit.data_ptr() == dict_owner.data_ptr():   # (a converted copy is a temporary: nothing to remember)
-            coherence = cached_coherence(dict_unit, dict_owner)   # (None until the same dictionary tensor comes a second time)
         # a batch large enough for the table to pay for itself within this one call gets it at once, new dictionary or not:
         # the table is A * A / 2 transforms, the launch it trims B (K - 1) A / 2, of which a third go (512 atoms, 64 steps:
         # 64 segments 3.75 -> 2.93 + 0.45 ms, 128 segments 7.3 -> 5.4 + 0.45 ms; 48 segments 3.21 -> 2.82 + 0.45: not yet)
-        if coherence is None and B >= 64 and B * (K - 1) >= 6 * A and not torch.cuda.is_current_stream_capturing() and \
-                lib().mp_coherence_workspace_bytes(A, L):
-            coherence = coherence_table(dict_unit)
+        coherence = cached_coherence(dict_unit, build_now=B >= 64 and B * (K - 1) >= 6 * A)
     nbytes = workspace_bytes(B, N, A, L, K, path)
     ws = torch.empty(nbytes + 256, dtype=torch.uint8, device=dev)
     off = (-ws.data_ptr()) % 256
@@ -375,6 +450,7 @@ def encode(signal, dict_unit, n_steps, path=MP_PATH_INCREMENTAL, flags=0, want_r
                                           _ptr(atom), _ptr(lag), _ptr(gain), _ptr(residual),
                                           ctypes.c_void_p(ws.data_ptr() + off), nbytes, _stream(signal))
             coherence.record_stream(torch.cuda.current_stream(dev))
+            _tls.lazy = True
         else:
             fn = lib().mp_encode_conv_f32 if conv_model else lib().mp_encode_f32
             rc = fn(_ptr(signal), B, N, _ptr(dict_unit), A, L, K, int(path), int(flags),
@@ -427,39 +503,74 @@ class EncodePlan:
         atom, lag, gain, residual = plan(signal)             # [B, N] -> views of the plan's static outputs
 
     The outputs are overwritten by the next call (clone what must outlive it).  As with encode(), a segment
-    whose FFT screen overflowed is marked with gain = NaN: encode_checked() is the checked, un-captured form."""
+    whose FFT screen overflowed is marked with gain = NaN: encode_checked() is the checked, un-captured form.
 
-    def __init__(self, batch, n_samples, dict_unit, n_steps, path=None, flags=0, want_residual=True, sub_batches=None):
+    The dictionary and the lazy screen.  `dict_unit` (when it is fp32 and contiguous, the caller's own tensor) is read
+    by every replay, so a training loop may update it in place between replays.  The lazy screen's coherence table is a
+    function of the dictionary, so the plan OWNS one (`lazy=True`, the default where the shape takes the persistent form)
+    together with a private copy of the dictionary it was computed from, and the captured graph begins with the
+    device-side comparison of _native.validated_table(): a replay whose dictionary differs from that copy runs with an
+    infinite table -- every tile screened, the plain encode, same events as any other schedule -- until
+    `plan.refresh_dictionary()` recomputes copy and table (mp_coherence_f32, ~0.45 ms at 512 x 512) into the same
+    buffers.  Nothing the graph reads belongs to a cache that could evict it."""
+
+    def __init__(self, batch, n_samples, dict_unit, n_steps, path=None, flags=0, want_residual=True, sub_batches=None,
+                 lazy=None):
         dict_unit = _f32(dict_unit)
         _require_cuda(dict_unit)
         self.path = default_path(dict_unit.shape[1]) if path is None else path
         self.dict_unit = dict_unit
         dev = dict_unit.device
+        A, L = dict_unit.shape
         self.signal = torch.zeros((int(batch), int(n_samples)), dtype=torch.float32, device=dev)
         # sub_batches=None: the library's choice for the shape (the persistent form where it applies, else two
         # sub-batches); a number: that many.  A per-call flag: nothing process-wide is touched while other threads encode
         if sub_batches is None:
-            encode(self.signal, dict_unit, n_steps, path=self.path, flags=int(flags), want_residual=False)
+            encode(self.signal, dict_unit, n_steps, path=self.path, flags=int(flags), want_residual=False, coherence=False)
             groups = 0 if last_schedule() == -1 else 2
         else:
             groups = max(2, min(4, int(sub_batches)))
-        args = dict(path=self.path, flags=int(flags) | (flag_groups(groups) if groups else 0), want_residual=want_residual)
+        if lazy is None:
+            lazy = (groups == 0 and self.path == MP_PATH_FFT and int(batch) >= LAZY_MIN_BATCH and int(n_steps) >= 8 and
+                    not (int(flags) & ~MP_FLAG_FFT_PERSISTENT))
+        self.lazy = bool(lazy) and self.path == MP_PATH_FFT and lib().mp_coherence_workspace_bytes(A, L) > 0
+        self._dict_copy = self._table = None
+        if self.lazy:
+            self._dict_copy = torch.empty_like(dict_unit)
+            self._table = torch.empty((A, (A + 31) // 32), dtype=torch.float32, device=dev)
+            self.refresh_dictionary()
+        self._args = dict(path=self.path, flags=int(flags) | (flag_groups(groups) if groups else 0),
+                          want_residual=want_residual)
         with torch.cuda.device(dev):
             init_streams(dev)  # the pool's self-test synchronises with the host: before the capture, not inside it
-        self._capture(dev, n_steps, args)
+        self._capture(dev, n_steps)
 
-    def _capture(self, dev, n_steps, args):
+    def refresh_dictionary(self):
+        """After an in-place update of the dictionary: recompute the plan's copy and coherence table (into the buffers
+        the captured graph reads), so that later replays skip transforms again.  Replays in between are exact without
+        it (every tile screened).  No-op for a plan without the lazy screen."""
+        if self.lazy:
+            self._dict_copy.copy_(self.dict_unit)
+            self._table.copy_(coherence_table(self._dict_copy))
+
+    def _encode(self, n_steps):
+        if not self.lazy:
+            return encode(self.signal, self.dict_unit, n_steps, coherence=False, **self._args)
+        table, _ = validated_table(self.dict_unit, self._dict_copy, self._table)
+        return encode(self.signal, self.dict_unit, n_steps, coherence=table, **self._args)
+
+    def _capture(self, dev, n_steps):
         side = torch.cuda.Stream(dev)
         side.wait_stream(torch.cuda.current_stream(dev))
         with torch.cuda.stream(side):  # warm-up outside the capture: kernel attributes, the stream pool
-            encode(self.signal, self.dict_unit, n_steps, **args)
+            self._encode(n_steps)
         torch.cuda.current_stream(dev).wait_stream(side)
         torch.cuda.synchronize(dev)
         self.graph = torch.cuda.CUDAGraph()
         # thread_local: only THIS thread's calls are checked while capturing -- another host thread may be encoding,
         # synchronising or allocating meanwhile (the default "global" mode invalidates the capture when it does)
         with torch.cuda.graph(self.graph, capture_error_mode="thread_local"):
-            self.outputs = encode(self.signal, self.dict_unit, n_steps, **args)
+            self.outputs = self._encode(n_steps)
 
     def __call__(self, signal):
         if signal.shape != self.signal.shape:

@@ -14,7 +14,8 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_LIB_PATH = os.path.join(_HERE, "_build", "libmp_oracle.so")
+# MP_ORACLE_LIB: another build of the same source (`make -C oracle asan`: the host-sanitizer build, tests only)
+_LIB_PATH = os.environ.get("MP_ORACLE_LIB") or os.path.join(_HERE, "_build", "libmp_oracle.so")
 _lib = None
 
 _i64 = ctypes.c_int64
@@ -27,7 +28,7 @@ def build(force=False):
     if force or not os.path.exists(_LIB_PATH) or (
         os.path.getmtime(_LIB_PATH) < os.path.getmtime(os.path.join(_HERE, "mp_oracle.c"))
     ):
-        subprocess.check_call(["make", "-C", _HERE, "-s"])
+        subprocess.check_call(["make", "-C", _HERE, "-s"] + (["asan"] if os.environ.get("MP_ORACLE_LIB") else []))
     return _LIB_PATH
 
 

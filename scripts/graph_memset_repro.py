@@ -1,0 +1,107 @@
+"""What went wrong with hipMemsetAsync inside a captured encode ("Clears are kernels, not memsets").
+
+mp_tune(MP_TUNE_CLEAR_MEMSET, 1) makes the encode clear its keys / flags / queue with hipMemsetAsync again, as round 2's
+first persistent form did.  The encode is captured and replayed four times in two settings:
+  A  as EncodePlan does it: the workspace is allocated INSIDE the capture (the graph's private pool);
+  B  the workspace is allocated before the capture (a static block).
+Every replay is compared with the un-captured encode; the persistent launch's error word (2: a queue word out of range,
+3: a dirty range out of range, 4: a slot past the queue, 1: a bounded wait gave up) and the marked segments tell what the
+launch found in the memory the memsets should have cleared.  The graph of setting A is written as DOT
+(gpurun_out/graph_memset_A.dot: node types, memset parameters, edges).  Run once; nothing here loops to provoke anything.
+"""
+import ctypes
+import os
+import sys
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "matching-pursuit_amd"))
+from mpcore import _native as nat  # noqa: E402
+from mpcore import synth  # noqa: E402
+
+OUT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "gpurun_out")
+os.makedirs(OUT, exist_ok=True)
+DEV = torch.device("cuda:0")
+A, L, N, B, K = 64, 256, 6000, 50, 9
+
+
+def raw_encode(x, du, ws, outs):
+    atom, lag, gain, res = outs
+    off = (-ws.data_ptr()) % 256
+    rc = nat.lib().mp_encode_f32(nat._ptr(x), B, N, nat._ptr(du), A, L, K, nat.MP_PATH_FFT, 0, nat._ptr(atom), nat._ptr(lag),
+                                 nat._ptr(gain), nat._ptr(res), ctypes.c_void_p(ws.data_ptr() + off), ws.numel() - 256,
+                                 nat._stream(x))
+    nat._check(rc, "mp_encode_f32")
+
+
+def main():
+    d = synth.make_dictionary(A, L, seed=61)
+    du = nat.unit_norm(torch.from_numpy(d).to(DEV))
+    x = torch.from_numpy(synth.make_segments(B, N, d, n_events=10, seed=62)).to(DEV)
+    ref = nat.encode(x, du, K, path=nat.MP_PATH_FFT, coherence=False)
+    torch.cuda.synchronize()
+    assert nat.last_schedule() == -1
+    nbytes = nat.workspace_bytes(B, N, A, L, K, nat.MP_PATH_FFT)
+    print(f"shape {A}x{L}, {B} x {N}, K={K}; workspace {nbytes} bytes")
+
+    def outputs():
+        return (torch.empty((B, K), dtype=torch.int64, device=DEV), torch.empty((B, K), dtype=torch.int64, device=DEV),
+                torch.empty((B, K), dtype=torch.float32, device=DEV), torch.empty((B, N), dtype=torch.float32, device=DEV))
+
+    for memset in (1, 0):
+        nat.tune(nat.MP_TUNE_CLEAR_MEMSET, memset)
+        for setting in ("A: workspace allocated inside the capture", "B: workspace allocated before the capture"):
+            inside = setting.startswith("A")
+            nat.init_streams(DEV)
+            side = torch.cuda.Stream(DEV)
+            side.wait_stream(torch.cuda.current_stream(DEV))
+            with torch.cuda.stream(side):
+                nat.encode(x, du, K, path=nat.MP_PATH_FFT, coherence=False)
+            torch.cuda.current_stream(DEV).wait_stream(side)
+            torch.cuda.synchronize()
+            outs = outputs()
+            ws = None if inside else torch.zeros(nbytes + 256, dtype=torch.uint8, device=DEV)
+            g = torch.cuda.CUDAGraph()
+            try:
+                g.enable_debug_mode()
+            except Exception as e:  # noqa: BLE001
+                print("enable_debug_mode:", e)
+            with torch.cuda.graph(g, capture_error_mode="thread_local"):
+                if inside:
+                    ws_in = torch.empty(nbytes + 256, dtype=torch.uint8, device=DEV)
+                    raw_encode(x, du, ws_in, outs)
+                else:
+                    raw_encode(x, du, ws, outs)
+            if memset and inside:
+                try:
+                    g.debug_dump(os.path.join(OUT, "graph_memset_A.dot"))
+                except Exception as e:  # noqa: BLE001
+                    print("debug_dump:", e)
+            print(f"clears by {'hipMemsetAsync' if memset else 'kernel'}; {setting}")
+            for rep in range(4):
+                g.replay()
+                torch.cuda.synchronize()
+                st = nat.persist_stats()
+                same = all(torch.equal(p, q) for p, q in zip(outs, ref))
+                marked = int(torch.isnan(outs[2]).any(dim=1).sum())
+                print(f"    replay {rep}: identical to the plain encode: {same}; segments marked {marked}/{B}; "
+                      f"launch error word {st['error']}, finished {st['finished']}, tasks {st['tasks']}")
+                if not same and rep == 1 and ws is not None:
+                    # what is in the workspace where zeros should be: the most frequent 8-byte values
+                    w64 = ws[(-ws.data_ptr()) % 256:][: (nbytes // 8) * 8].view(torch.int64)
+                    vals, counts = torch.unique(w64, return_counts=True)
+                    top = torch.argsort(counts, descending=True)[:4]
+                    print("        workspace at", hex(ws.data_ptr()), "outputs at", [hex(t.data_ptr()) for t in outs],
+                          "x at", hex(x.data_ptr()), "du at", hex(du.data_ptr()))
+                    for i in top.tolist():
+                        v = int(vals[i]) & 0xffffffffffffffff
+                        where = torch.nonzero(w64 == vals[i]).flatten()
+                        print(f"        8-byte value {v:#018x} x {int(counts[i])}, first at byte offset {int(where[0]) * 8}, "
+                              f"last at {int(where[-1]) * 8}")
+            del g
+    nat.tune(nat.MP_TUNE_CLEAR_MEMSET, 0)
+
+
+if __name__ == "__main__":
+    main()

@@ -471,6 +471,31 @@ def loss_and_approx_fixtures(mp, conv, norm):
     print("  multi-channel: sparse_code raises", raised, "| decoder channels", dec.shape)
 
 
+def config3_fixture(mp, norm):
+    """BASELINE configs[3]'s shape -- 4096 x 2048 dictionary, 131072-sample segments -- through the reference's
+    sparse_code (modules/matchingpursuit.py:269-328), 2 segments x 4 steps: ~18 TFLOP of F.conv1d and a 4.3 GB feature
+    map per step, a few minutes on 8 cores.  The 32 MiB dictionary is NOT stored: it is synth.make_dictionary(4096,
+    2048, seed) again (numpy PCG64: a stable stream); the fixture keeps its seed, a float64 checksum of the reference's
+    unit_norm of it and that normalised dictionary's first four rows, so that a test can tell a different dictionary
+    from a different encode."""
+    A, L, N, B, K, n_ev, seed = 4096, 2048, 131072, 2, 4, 12, 1404
+    d = synth.make_dictionary(A, L, seed=seed)
+    x = synth.make_segments(B, N, d, n_events=n_ev, seed=seed)
+    out = run_encode(mp, torch.from_numpy(x)[:, None, :], torch.from_numpy(d), K)
+    d_unit = norm.unit_norm(torch.from_numpy(d)).numpy()
+    gap = (out["top2"][..., 0] - out["top2"][..., 1]) / np.abs(out["top2"][..., 0])
+    rdb = 20 * np.log10(np.linalg.norm(out["residual"], axis=-1) / np.linalg.norm(x, axis=-1))
+    np.savez_compressed(os.path.join(HERE, "encode_c4shape_4096x2048_n131072_b2_k4.npz"), signal=x,
+                        atom=out["atom"], lag=out["lag"], gain=out["gain"], top2=out["top2"],
+                        flat_order=out["flat_order"], residual=out["residual"], residual_db=rdb.astype(np.float64),
+                        seed=np.int64(seed), shape=np.array([A, L, N, B, K], dtype=np.int64),
+                        d_unit_sum=np.float64(d_unit.astype(np.float64).sum()),
+                        d_unit_abs_sum=np.float64(np.abs(d_unit.astype(np.float64)).sum()),
+                        d_unit_head=d_unit[:4].astype(np.float32))
+    print(f"  c4shape: min relative top-2 gap {gap.min():.3e}; residual dB {rdb.tolist()}; atoms {out['atom'].tolist()}; "
+          f"lags {out['lag'].tolist()}")
+
+
 if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "loss":  # only the loss / approximate-correlation fixtures
         torch.manual_seed(0)
@@ -486,5 +511,11 @@ if __name__ == "__main__":
         torch.set_num_threads(8)
         _mp, _conv, _norm, _stft, _ns = load_reference()
         lcn_fixtures(_mp, _norm)
+    elif len(sys.argv) > 1 and sys.argv[1] == "c4":  # only the configs[3]-shape encode (minutes of CPU)
+        torch.manual_seed(0)
+        torch.set_num_threads(8)
+        _mp, _conv, _norm, _stft, _ns = load_reference()
+        config3_fixture(_mp, _norm)
     else:
         main()
+        config3_fixture(*[load_reference()[i] for i in (0, 2)])

@@ -6,6 +6,8 @@ import ctypes
 import inspect
 import os
 import re
+import subprocess
+import sys
 
 import numpy as np
 import pytest
@@ -200,3 +202,39 @@ def test_dictionary_levels_host_helper_matches_brute_force():
         assert n_levels == int(want_level.max()) + 1
     level, overlap, n_levels = nat.dictionary_levels(np.zeros(1, dtype=np.int64), np.zeros(0), np.zeros(0), 8)
     assert n_levels == 0 and level.shape == (0,)
+
+
+# ---- host sanitizers ("ASan host build of the CPU restatement"; CPU only -- the GPU pool has none) ----
+def _sanitizer_runtime(name):
+    out = subprocess.run(["gcc", f"-print-file-name={name}"], capture_output=True, text=True).stdout.strip()
+    return out if os.path.isabs(out) and os.path.exists(out) else None
+
+
+def test_levels_helper_under_host_sanitizers(tmp_path):
+    """csrc/mplevels.inc -- the host C++ behind mp_dictionary_levels_host, working on caller-supplied index arrays --
+    built on its own with -fsanitize=address,undefined and run over 400 random event sets against a brute-force
+    restatement (tests/native/levels_sanitize.cpp)."""
+    if _sanitizer_runtime("libasan.so") is None:
+        pytest.skip("gcc has no libasan here")
+    exe = str(tmp_path / "levels_sanitize")
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=all",
+                           "-o", exe, os.path.join(REPO, "tests", "native", "levels_sanitize.cpp")])
+    run = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    assert run.returncode == 0 and "levels_sanitize ok" in run.stdout, run.stdout + run.stderr
+
+
+def test_oracle_under_host_sanitizers():
+    """oracle/mp_oracle.c built with -fsanitize=address,undefined (make -C oracle asan) reproduces the reference's
+    fixtures with no report: the small encode, LCN, primitive, dictionary-update and loss cases here (the 512 x 512 and
+    4096 x 2048 shapes, minutes under ASan, run with `make -C oracle check-asan`)."""
+    asan, ubsan = _sanitizer_runtime("libasan.so"), _sanitizer_runtime("libubsan.so")
+    if asan is None or ubsan is None:
+        pytest.skip("gcc has no sanitizer runtimes here")
+    subprocess.check_call(["make", "-C", os.path.join(REPO, "oracle"), "-s", "asan"])
+    env = dict(os.environ, MP_ORACLE_LIB=os.path.join(REPO, "oracle", "_build", "libmp_oracle_asan.so"),
+               LD_PRELOAD=f"{asan} {ubsan}", ASAN_OPTIONS="detect_leaks=0:abort_on_error=1", UBSAN_OPTIONS="halt_on_error=1")
+    run = subprocess.run([sys.executable, "-m", "pytest", os.path.join(REPO, "tests", "test_oracle_golden.py"), "-x", "-q",
+                          "-p", "no:cacheprovider", "-k", "not config3_shape and not c2shape"],
+                         env=env, capture_output=True, text=True, timeout=900, cwd=REPO)
+    assert run.returncode == 0, run.stdout[-3000:] + run.stderr[-3000:]
+    assert "passed" in run.stdout and "AddressSanitizer" not in run.stderr and "runtime error" not in run.stderr

@@ -107,11 +107,39 @@ def test_encode_bitwise_vs_oracle(oracle, shape, pname, path, flags):
     assert np.array_equal(residual, want["residual"])
 
 
+# the schedules a reference-generated fixture is put through: the library default for the shape (mp_last_schedule tells
+# which form that was), the persistent form forced, with the lazy screen, the launch-per-step forms, and the two
+# direct-correlation schedules
+GOLDEN_SCHEDULES = [
+    ("fft_default", nat.MP_PATH_FFT, 0, False),
+    ("fft_persistent", nat.MP_PATH_FFT, nat.MP_FLAG_FFT_PERSISTENT, False),
+    ("fft_persistent_lazy", nat.MP_PATH_FFT, nat.MP_FLAG_FFT_PERSISTENT, True),
+    ("fft_no_persistent", nat.MP_PATH_FFT, nat.MP_FLAG_FFT_NO_PERSISTENT, False),
+    ("fft_one_stream", nat.MP_PATH_FFT, nat.MP_FLAG_NO_OVERLAP, False),
+    ("incremental", nat.MP_PATH_INCREMENTAL, 0, False),
+    ("direct", nat.MP_PATH_DIRECT, 0, False),
+]
+
+
+def _check_against_reference_fixture(z, du, got):
+    atom, lag, gain, residual = got
+    gap = (z["top2"][..., 0] - z["top2"][..., 1]) / np.abs(z["top2"][..., 0])
+    assert gap.min() >= 1e-4
+    assert not np.isnan(gain).any()
+    assert np.array_equal(atom, z["atom"]) and np.array_equal(lag, z["lag"])
+    assert np.abs(gain - z["gain"]).max() <= REL * np.abs(z["gain"]).max()
+    assert np.abs(residual - z["residual"]).max() <= REL * np.abs(z["signal"]).max()
+    rdb = 20 * np.log10(np.linalg.norm(residual, axis=-1) / np.linalg.norm(z["signal"], axis=-1))
+    assert np.abs(rdb - z["residual_db"]).max() <= 1e-3
+
+
+@pytest.mark.parametrize("sname,path,flags,lazy", GOLDEN_SCHEDULES)
 @pytest.mark.parametrize("name", ["encode_c1_16x256_n8192_b1_k8", "encode_mid_64x128_n4096_b3_k16",
                                   "encode_ragged_24x100_n1000_b2_k12",
                                   "encode_c2shape_512x512_n32768_b2_k12"])
-def test_encode_matches_reference_golden(golden_dir, name):
-    """Against vectors produced by the real reference (tests/golden/generate_golden.py)."""
+def test_encode_matches_reference_golden(golden_dir, name, sname, path, flags, lazy):
+    """Against vectors produced by the real reference (tests/golden/generate_golden.py), on every schedule -- the
+    configs[1]-shape fixture meets the persistent FFT form (the library default there) directly, not through the oracle."""
     z = np.load(os.path.join(golden_dir, name + ".npz"))
     if "d_raw" in z.files:
         d_raw = z["d_raw"]
@@ -121,15 +149,60 @@ def test_encode_matches_reference_golden(golden_dir, name):
     K = z["atom"].shape[1]
     du = nat.unit_norm(torch.from_numpy(d_raw).to(DEV))
     assert np.abs(du.cpu().numpy() - z["d_unit"]).max() <= 2e-7
-    atom, lag, gain, residual = [t.cpu().numpy() for t in
-                                 nat.encode(torch.from_numpy(z["signal"]).to(DEV), du, K)]
-    gap = (z["top2"][..., 0] - z["top2"][..., 1]) / np.abs(z["top2"][..., 0])
-    assert gap.min() >= 1e-4
-    assert np.array_equal(atom, z["atom"]) and np.array_equal(lag, z["lag"])
-    assert np.abs(gain - z["gain"]).max() <= REL * np.abs(z["gain"]).max()
-    assert np.abs(residual - z["residual"]).max() <= REL * np.abs(z["signal"]).max()
-    rdb = 20 * np.log10(np.linalg.norm(residual, axis=-1) / np.linalg.norm(z["signal"], axis=-1))
-    assert np.abs(rdb - z["residual_db"]).max() <= 1e-3
+    co = False
+    if lazy:
+        if nat.lib().mp_coherence_workspace_bytes(*du.shape) == 0:
+            pytest.skip("the lazy screen does not cover this transform size")
+        co = nat.coherence_table(du)
+    got = [t.cpu().numpy() for t in nat.encode(torch.from_numpy(z["signal"]).to(DEV), du, K, path=path, flags=flags,
+                                               coherence=co)]
+    if name.startswith("encode_c2shape") and sname in ("fft_default", "fft_persistent", "fft_persistent_lazy"):
+        assert nat.last_schedule() == -1 and nat.persist_stats()["error"] == 0   # (the one-launch form is what ran)
+    _check_against_reference_fixture(z, du, got)
+
+
+C4_FIXTURE = "encode_c4shape_4096x2048_n131072_b2_k4"
+
+
+def _c4_fixture(golden_dir):
+    z = np.load(os.path.join(golden_dir, C4_FIXTURE + ".npz"))
+    A, L, N, B, K = [int(v) for v in z["shape"]]
+    d_raw = synth.make_dictionary(A, L, seed=int(z["seed"]))          # (32 MiB: regenerated, not stored)
+    du = nat.unit_norm(torch.from_numpy(d_raw).to(DEV))
+    du_host = du.cpu().numpy()
+    # the dictionary the reference normalised: float64 checksums and the first rows, stored with the fixture
+    assert abs(du_host.astype(np.float64).sum() - float(z["d_unit_sum"])) <= 1e-4
+    assert abs(np.abs(du_host.astype(np.float64)).sum() - float(z["d_unit_abs_sum"])) <= 1e-9 * float(z["d_unit_abs_sum"])
+    assert np.abs(du_host[:4] - z["d_unit_head"]).max() <= 2e-7
+    return z, du, du_host, K
+
+
+@pytest.mark.parametrize("sname,path,flags", [("fft_default", nat.MP_PATH_FFT, 0),
+                                              ("fft_no_persistent", nat.MP_PATH_FFT, nat.MP_FLAG_FFT_NO_PERSISTENT),
+                                              ("fft_one_stream", nat.MP_PATH_FFT, nat.MP_FLAG_NO_OVERLAP),
+                                              ("incremental", nat.MP_PATH_INCREMENTAL, 0)])
+def test_config3_shape_matches_reference_golden(golden_dir, sname, path, flags):
+    """BASELINE configs[3]'s shape (4096 x 2048 dictionary, 131072-sample segments: 8192-point transforms, 128 atom
+    tiles, 2048 blocks per segment) against the REFERENCE's own sparse_code run at that size
+    (/root/reference/modules/matchingpursuit.py:269-328; 2 segments x 4 steps, generated by
+    tests/golden/generate_golden.py c4): picks exact, gains and residual to 1e-5, residual dB to 1e-3."""
+    z, du, _, K = _c4_fixture(golden_dir)
+    got = [t.cpu().numpy() for t in nat.encode(torch.from_numpy(z["signal"]).to(DEV), du, K, path=path, flags=flags,
+                                               coherence=False)]
+    _check_against_reference_fixture(z, du, got)
+
+
+def test_config3_shape_bitwise_vs_oracle(oracle, golden_dir):
+    """... and against the oracle at that shape, bit for bit, on the library default (2 segments x 4 steps: ~20 s of
+    oracle on the box's 16 CPUs), with the oracle itself held to the reference's fixture in the same breath."""
+    z, du, du_host, K = _c4_fixture(golden_dir)
+    want = oracle.encode(z["signal"], du_host, K)
+    assert np.array_equal(want["atom"], z["atom"]) and np.array_equal(want["lag"], z["lag"])
+    assert np.abs(want["gain"] - z["gain"]).max() <= REL * np.abs(z["gain"]).max()
+    atom, lag, gain, residual = [t.cpu().numpy() for t in nat.encode(torch.from_numpy(z["signal"]).to(DEV), du, K,
+                                                                     path=nat.MP_PATH_FFT)]
+    assert np.array_equal(atom, want["atom"]) and np.array_equal(lag, want["lag"])
+    assert np.array_equal(gain, want["gain"]) and np.array_equal(residual, want["residual"])
 
 
 LCN_GOLDEN = ["encode_lcn_24x100_n1000_b2_k10", "encode_lcn_64x128_n4096_b3_k12", "encode_lcn_7x33_n300_b2_k6"]
@@ -797,17 +870,21 @@ def test_lazy_screen_is_bit_identical_to_the_oracle(oracle):
                     skipped += st["skipped"]
         assert skipped > 1000
         nat.tune(nat.MP_TUNE_LAZY_MARGIN, 0.7)
-        # the automatic form: the same dictionary TENSOR a second time gets its table; a flag that names another form does not
-        nat._coherence_cache.clear()
-        nat.encode(x, du, K, path=nat.MP_PATH_FFT)
-        assert nat.persist_stats()["skipped"] == 0
-        out = nat.encode(x, du, K, path=nat.MP_PATH_FFT)
+        # the automatic form: a dictionary that comes again with the same CONTENT gets its table (remembered at the first
+        # call, seen equal at the second, table from the third); a flag that names another form does not
+        nat.clear_caches()
+        for call in range(2):
+            nat.encode(x, du, K, path=nat.MP_PATH_FFT)
+            torch.cuda.synchronize()
+            assert nat.persist_stats()["skipped"] == 0, call
+        out = nat.encode(x, du.clone(), K, path=nat.MP_PATH_FFT)      # (another tensor object, same content)
+        torch.cuda.synchronize()
         assert nat.persist_stats()["skipped"] > 0
         assert np.array_equal(out[0].cpu().numpy(), want["atom"]) and np.array_equal(out[2].cpu().numpy(), want["gain"])
         nat.encode(x, du, K, path=nat.MP_PATH_FFT, coherence=False)
         assert nat.persist_stats()["skipped"] == 0
         # a batch large enough to pay for the table within one call gets it at the first sighting of its dictionary
-        nat._coherence_cache.clear()
+        nat.clear_caches()
         d = synth.make_dictionary(200, 256, seed=77)
         du2 = nat.unit_norm(torch.from_numpy(d).to(DEV))
         x2 = torch.from_numpy(synth.make_segments(100, 6000, d, n_events=30, seed=78)).to(DEV)
@@ -904,6 +981,41 @@ def test_persistent_form_replayed_from_a_graph(oracle):
         assert np.array_equal(a.cpu().numpy(), want["atom"]) and np.array_equal(l.cpu().numpy(), want["lag"]), rep
         assert np.array_equal(g.cpu().numpy(), want["gain"]) and np.array_equal(r.cpu().numpy(), want["residual"]), rep
     assert nat.persist_stats()["error"] == 0
+
+
+def test_plan_replayed_after_an_in_place_dictionary_update(oracle):
+    """An EncodePlan reads its dictionary at replay time, and owns the lazy screen's coherence table: the captured graph
+    compares the live dictionary with the plan's copy on the device, so a replay after an in-place update -- through
+    `.data`, which no version counter sees -- runs with an infinite table (every tile screened) and still returns the
+    oracle's events for the NEW dictionary; after refresh_dictionary() replays skip transforms again.  The table does
+    not belong to any cache (clear_caches() between replays changes nothing)."""
+    A, L, N, B, K = 64, 256, 6000, 40, 12
+    d1, d2 = synth.make_dictionary(A, L, seed=161), synth.make_dictionary(A, L, seed=162)
+    du1, du2 = oracle.unit_norm(d1), oracle.unit_norm(d2)
+    x_host = synth.make_segments(B, N, d1, n_events=10, seed=163) + synth.make_segments(B, N, d2, n_events=10, seed=164)
+    x = torch.from_numpy(x_host).to(DEV)
+    du = torch.from_numpy(du1).to(DEV)
+    plan = nat.EncodePlan(B, N, du, K)
+    assert plan.lazy and plan.dict_unit.data_ptr() == du.data_ptr()
+
+    def check(want, tag):
+        a, l, g, r = plan(x)
+        torch.cuda.synchronize()
+        st = nat.persist_stats()
+        assert st["error"] == 0 and not torch.isnan(g).any(), tag
+        assert np.array_equal(a.cpu().numpy(), want["atom"]) and np.array_equal(l.cpu().numpy(), want["lag"]), tag
+        assert np.array_equal(g.cpu().numpy(), want["gain"]) and np.array_equal(r.cpu().numpy(), want["residual"]), tag
+        return st["skipped"]
+
+    want1, want2 = oracle.encode(x_host, du1, K), oracle.encode(x_host, du2, K)
+    assert check(want1, "first dictionary") > 0
+    du.data[:] = torch.from_numpy(du2).to(DEV)           # behind torch's back: du._version does not move
+    nat.clear_caches()
+    assert check(want2, "updated in place, stale table") == 0
+    plan.refresh_dictionary()
+    assert check(want2, "refreshed") > 0
+    du.data[:] = torch.from_numpy(du1).to(DEV)
+    assert check(want1, "back to the first dictionary, table of the second") == 0
 
 
 # ---- BASELINE.json configs at FULL size --------------------------------------------------------------------------

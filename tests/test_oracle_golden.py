@@ -58,6 +58,24 @@ def test_oracle_encode_matches_reference(oracle, golden_dir, name):
 LCN_GOLDEN = ["encode_lcn_24x100_n1000_b2_k10", "encode_lcn_64x128_n4096_b3_k12", "encode_lcn_7x33_n300_b2_k6"]
 
 
+def test_oracle_matches_reference_at_the_config3_shape(oracle, golden_dir):
+    """BASELINE configs[3]'s shape (4096 x 2048 dictionary, 131072-sample segments): the oracle against the reference's
+    own sparse_code at that size -- both segments, the first two of the fixture's four steps (~25 s on 8 CPUs; the GPU
+    suite walks all four).  The dictionary is regenerated from its seed and checked against the fixture's checksums."""
+    z = np.load(os.path.join(golden_dir, "encode_c4shape_4096x2048_n131072_b2_k4.npz"))
+    A, L, N, B, K = [int(v) for v in z["shape"]]
+    du = oracle.unit_norm(synth.make_dictionary(A, L, seed=int(z["seed"])))
+    assert abs(du.astype(np.float64).sum() - float(z["d_unit_sum"])) <= 1e-4
+    assert np.abs(du[:4] - z["d_unit_head"]).max() <= 2e-7
+    gap = (z["top2"][..., 0] - z["top2"][..., 1]) / np.abs(z["top2"][..., 0])
+    assert gap.min() >= 1e-4
+    steps = 2
+    out = oracle.encode(z["signal"], du, steps)
+    assert np.array_equal(out["atom"], z["atom"][:, :steps]) and np.array_equal(out["lag"], z["lag"][:, :steps])
+    assert np.abs(out["gain"] - z["gain"][:, :steps]).max() <= REL * np.abs(z["gain"]).max()
+    assert np.abs(out["top2"] - z["top2"][:, :steps]).max() <= REL * np.abs(z["top2"]).max()
+
+
 @pytest.mark.parametrize("name", LCN_GOLDEN)
 def test_oracle_local_contrast_norm_matches_reference(oracle, golden_dir, name):
     """sparse_code(local_contrast_norm=True), matchingpursuit.py:284-294: the selection rule on the
