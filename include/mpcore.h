@@ -226,8 +226,11 @@ int mp_encode_lazy_f32(const float *signal, int64_t B, int64_t N, const float *d
                        float *out_residual, void *workspace, size_t workspace_bytes, void *stream);
 
 /* The coherence table mp_encode_lazy_f32 takes, computed on the device: out[A][ceil(A / 32)] (one full-pass FFT screen of
- * the atoms against the dictionary: ~0.3 ms at 512 x 512).  Exists where the lazy screen does (1024- to 4096-point
- * transforms: 63 <= L <= 1302); mp_coherence_workspace_bytes returns 0 otherwise. */
+ * the atoms against the dictionary: ~0.3 ms at 512 x 512, ~90 ms at 4096 x 2048).  Exists where the lazy screen does
+ * (1024- to 8192-point transforms: 63 <= L <= 2667); mp_coherence_workspace_bytes returns 0 otherwise.  Which encodes use
+ * the table: the persistent form (its select decides inside the launch), and the launch-per-step form whose select is
+ * the fused whole-cell kernel with block summaries (>= 65536 cells per segment, or > 16384 with L <= 512 -- BASELINE
+ * configs[3]'s shape): there the select leaves a tile mask the next screen launch obeys.  Other forms ignore it. */
 size_t mp_coherence_workspace_bytes(int64_t A, int64_t L);
 int mp_coherence_f32(const float *dict_unit, int64_t A, int64_t L, float *out, void *workspace, size_t workspace_bytes,
                      void *stream);
@@ -243,6 +246,11 @@ int mp_last_schedule(void);
  * quarters + chains, event + next window, transform + stores), [13] = selects counted, [14] = screen tasks answered without
  * a transform (lazy screen).  Synchronises the device. */
 int mp_persist_stats(uint64_t *out16);
+
+/* Debug: the lazy screen of the launch-per-step form since the last read, summed over encodes -- out2[0] = (segment,
+ * tile) screens skipped (their dirty cells kept widened bounds), out2[1] = (segment, tile) decisions made.  Synchronises
+ * the device; resets the counters. */
+int mp_lazy_stats(uint64_t *out2);
 
 /* Debug (MP_TUNE_AUDIT): the largest |screen - exact| / eps over all cells audited since the last read, their
  * number, the same for quarter-cell maxima, and how many exceeded 1 (must be 0).  Synchronises the device;

@@ -1079,6 +1079,7 @@ __global__ __launch_bounds__(1024) void dictionary_update_level_kernel(
 // Workspace carving (all offsets multiples of 256 bytes)
 // ------------------------------------------------------------------------------------------------
 #include "mpfft.inc"
+#include "mplazy.inc"
 #include "mplevels.inc"
 
 // bytes of the persistent form's control block + ticket lines + queue (mppersist.inc: PersistCtl <= 256, 512 lines of 64,
@@ -1104,6 +1105,8 @@ struct Workspace {
     u64 *ekeys;
     char *pctl;     // persistent schedule: control block + queue entries (mppersist.inc); nullptr if the shape is not eligible
     cpx *xrec;      // ... and the per-(segment, step) window records
+    unsigned *skip; // lazy screen, launch-per-step form: [B][4] tile masks (select -> next screen launch)
+    float *lfloor;  // ... and the run's floor per segment [B] (persist_floor_*_kernel after step 0)
     size_t bytes;
 };
 
@@ -1132,6 +1135,8 @@ Workspace carve(const Geom &g, int path, char *base, int K = 0) {
     w.bsum = nullptr;
     w.pctl = nullptr;
     w.xrec = nullptr;
+    w.skip = nullptr;
+    w.lfloor = nullptr;
     if (path == MP_PATH_FFT) {
         FftGeom f;
         if (make_fft_geom(g, &f)) {
@@ -1148,6 +1153,8 @@ Workspace carve(const Geom &g, int path, char *base, int K = 0) {
             size_t o_bs = take((size_t)g.B * g.NBLK * 2 * sizeof(unsigned));
             const bool quarters = (int64_t)g.NBLK * g.NAT <= QUARTER_MAX_CELLS;
             size_t o_sk = take(quarters ? (size_t)g.B * g.NBLK * g.NAT * SUBCELLS * sizeof(float) : 0);
+            size_t o_lz = take((size_t)g.B * 4 * sizeof(unsigned));
+            size_t o_lf = take((size_t)g.B * sizeof(float));
             w.tw = reinterpret_cast<cpx *>(base + o_tw);
             w.pspec = reinterpret_cast<cpx *>(base + o_ps);
             w.xspec = reinterpret_cast<cpx *>(base + o_xs);
@@ -1160,6 +1167,8 @@ Workspace carve(const Geom &g, int path, char *base, int K = 0) {
             w.dscale = reinterpret_cast<float *>(base + o_ds);
             w.bsum = reinterpret_cast<unsigned *>(base + o_bs);
             if (quarters) w.subk = reinterpret_cast<float *>(base + o_sk);
+            w.skip = reinterpret_cast<unsigned *>(base + o_lz);
+            w.lfloor = reinterpret_cast<float *>(base + o_lf);
             // persistent schedule (mppersist.inc): queue + one window record per (segment, step >= 2)
             // (one write-once window record per segment and step: not for batches whose records would pass 2 GiB --
             //  those run launch per step)
@@ -1443,6 +1452,7 @@ int fft_setup(const Geom &g, const Workspace &w, const float *du, int flags, int
     cl.add(w.bsum, (size_t)g.B * g.NBLK * 2 * sizeof(unsigned));
     cl.add(w.keys, (size_t)g.B * n_cells * sizeof(u64));
     cl.add(w.dscale, sizeof(float));
+    cl.add(w.skip, (size_t)g.B * 4 * sizeof(unsigned));
     if (w.pctl && K >= 2) cl.add(w.pctl, persist_ctl_bytes(g.B, K));   // the persistent form's control block and queue
     if ((rc = clear_async(cl, st))) return rc;
     if (f.split) {  // long atoms: two half-size transforms per M-point transform (mpfft.inc)
@@ -1479,7 +1489,7 @@ int fft_setup(const Geom &g, const Workspace &w, const float *du, int flags, int
 
 // one matching-pursuit step of a (sub-)batch on stream st
 int fft_iteration(const Geom &g, const Workspace &w, const float *du, int K, int k, int flags, int64_t *out_atom,
-                  int64_t *out_lag, float *out_gain, const Rule &rule, hipStream_t st) {
+                  int64_t *out_lag, float *out_gain, const Rule &rule, hipStream_t st, const LazyArgs &lz = LazyArgs()) {
     FftGeom f;
     if (!make_fft_geom(g, &f)) return fail(MP_ERR_UNSUPPORTED, "MP_PATH_FFT: atom too long%s");
     const float tau = fft_tau(f.logM).tau;
@@ -1515,6 +1525,13 @@ int fft_iteration(const Geom &g, const Workspace &w, const float *du, int K, int
     // (kept up to date by fft_screen_kernel only: not with the plain radix-4 screen)
     unsigned *bsum = (fused && n_cells > QUARTER_MAX_CELLS && f.logM >= 10 && !(flags & MP_FLAG_FFT_SIMPLE)) ? w.bsum : nullptr;
     if ((flags & MP_FLAG_FFT_PERSISTENT_BIT) && quarter) bsum = w.bsum;  // step 0 of the persistent schedule builds them too
+    // The lazy screen on this form: the fused select decides, per segment, which tiles' dirty cells keep
+    // their widened bounds -- a [B][4] mask the NEXT screen launch's workgroups leave on (config-4 shape: 8192-point
+    // transforms, where the launch-per-step form is work-bound on its screens).  From step 1's select on: the floor it
+    // needs comes from the summaries step 0 leaves (below).
+    const bool lazy_form = lz.mu != nullptr && fused && !quarter && bsum != nullptr && w.skip != nullptr && !f.split &&
+                           f.logM >= 10 && g.NAT <= 128 && !(flags & (MP_FLAG_FFT_SIMPLE | MP_FLAG_INTERNAL_COHERENCE)) &&
+                           !audit_on.load(std::memory_order_relaxed);
     {
         const int *dirty = k == 0 ? nullptr : w.dirty;
         const int nw = k == 0 ? f.NW : 1;
@@ -1567,19 +1584,20 @@ int fft_iteration(const Geom &g, const Workspace &w, const float *du, int K, int
                 const unsigned gwp = nw * (16 / (C::SLOTS * pps));
                 const dim3 grid = seg_fast ? dim3((unsigned)g.B, gwp, g.NAT) : dim3(gwp, g.NAT, (unsigned)g.B);
                 if (flags & MP_FLAG_INTERNAL_COHERENCE) {   // mp_coherence_f32: cell maxima of |correlation|, nothing after the screen
-                    constexpr int LC = LS <= 12 ? LS : 12;  // (only sizes the persistent form takes get here)
+                    constexpr int LC = LS <= 13 ? LS : 13;  // (coherence_geom: 1024- to 8192-point transforms)
                     auto kabs = (fft_screen_kernel<LC, true>);
                     if ((rc = fft_lds_attr(kabs, lds_s))) return rc;
                     hipLaunchKernelGGL(kabs, grid, dim3(C::WG), lds_s, st, w.xspec, w.pspec, w.tw, dirty, w.wnorm, w.keys, w.ceps,
                                        g.N, g.A, g.NBLK, g.NAT, f.V, f.NW, tau, pps, (int)seg_fast, (float *)nullptr,
-                                       (unsigned *)nullptr);
+                                       (unsigned *)nullptr, (const unsigned *)nullptr);
                     HIP_TRY(hipGetLastError());
                     g_prof.end(st);
                     return MP_OK;
                 }
                 if ((rc = fft_lds_attr(fft_screen_kernel<LS>, lds_s))) return rc;
                 hipLaunchKernelGGL(fft_screen_kernel<LS>, grid, dim3(C::WG), lds_s, st, w.xspec, w.pspec, w.tw, dirty,
-                                   w.wnorm, w.keys, w.ceps, g.N, g.A, g.NBLK, g.NAT, f.V, f.NW, tau, pps, (int)seg_fast, subk, bsum);
+                                   w.wnorm, w.keys, w.ceps, g.N, g.A, g.NBLK, g.NAT, f.V, f.NW, tau, pps, (int)seg_fast, subk, bsum,
+                                   (const unsigned *)(lazy_form && k >= 2 ? w.skip : nullptr));
             } else {
                 hipLaunchKernelGGL(fft_correlate_kernel<LG>, dim3(nw, g.NAT, (unsigned)g.B), dim3(256), lds, st,
                                    w.xspec, w.pspec, w.tw, dirty, w.wnorm, w.keys, w.ceps, g.N, g.A, g.NBLK,
@@ -1615,8 +1633,21 @@ int fft_iteration(const Geom &g, const Workspace &w, const float *du, int K, int
                 hipLaunchKernelGGL(fft_select_fused_kernel<LT>, dim3((unsigned)g.B), dim3(1024), lds_f, st, w.keys,
                                    w.ceps, n_cells, w.res, du, w.dirty, w.overflow, out_atom, out_lag, out_gain,
                                    g.N, g.A, g.L, g.Ns, g.NBLK, g.NAT, K, k, rule.du_sub, rule.shift, rule.square,
-                                   w.tw, w.xspec, w.wnorm, f.NW, (const float *)w.dscale, bsum);
+                                   w.tw, w.xspec, w.wnorm, f.NW, (const float *)w.dscale, bsum,
+                                   lazy_form && k >= 1 ? lz.mu : (const float *)nullptr, tau, lz.margin, lz.reuse,
+                                   (const float *)w.lfloor, lazy_form && k >= 1 ? w.skip : (unsigned *)nullptr);
             })
+            if (lazy_form && k == 0 && K > 2) {
+                // the lazy screen's floor: where this run's maxima are expected to end (mppersist.inc: rank K + K/16 + 1,
+                // peaks dominating `radius` blocks either side), from the summaries after step 0's select
+                const int radius = lazy_radius_for(g.L);
+                if (g.NBLK <= FLOOR_WAVE_MAXBLK)
+                    hipLaunchKernelGGL(persist_floor_wave_kernel, dim3((unsigned)g.B), dim3(64), 0, st, (const unsigned *)w.bsum,
+                                       g.NBLK, K + K / 16 + 1, radius, w.lfloor);
+                else
+                    hipLaunchKernelGGL(persist_floor_kernel, dim3((unsigned)g.B), dim3(256), 0, st, (const unsigned *)w.bsum,
+                                       g.NBLK, K + K / 16 + 1, radius, w.lfloor);
+            }
         } else {
             // select-A merged into the refinement launch when select-B is the kernel that clears the slots
             // afterwards and a segment's keys are few enough for every workgroup to scan them
@@ -1771,6 +1802,8 @@ Workspace sub_batch(const Workspace &w, const Geom &g, int path, int64_t b0, int
         v.ekeys = w.ekeys + b0 * (MAXCONT + 1);
         if (w.subk) v.subk = w.subk + b0 * cells * SUBCELLS;
         v.bsum = w.bsum + b0 * g.NBLK * 2;
+        if (w.skip) v.skip = w.skip + b0 * 4;
+        if (w.lfloor) v.lfloor = w.lfloor + b0;
     }
     return v;
 }
@@ -1820,7 +1853,7 @@ __global__ void coherence_reduce_kernel(const u64 *__restrict__ keys, const floa
 static bool coherence_geom(int64_t A, int64_t L, Geom *g, FftGeom *f) {
     if (A <= 0 || L <= 0) return false;
     *g = make_geom_for(A, 3 * L - 2, A, L, MP_PATH_FFT, 0);
-    return make_fft_geom(*g, f) && !f->split && f->logM >= 10 && f->logM <= 12;
+    return make_fft_geom(*g, f) && !f->split && f->logM >= 10 && f->logM <= 13;
 }
 size_t mp_coherence_workspace_bytes(int64_t A, int64_t L) {
     Geom g;
@@ -1834,7 +1867,7 @@ int mp_coherence_f32(const float *dict_unit, int64_t A, int64_t L, float *out, v
     FftGeom f;
     if (!dict_unit || !out || !workspace) return fail(MP_ERR_ARG, "mp_coherence_f32: null argument%s");
     if (!coherence_geom(A, L, &g, &f))
-        return fail(MP_ERR_UNSUPPORTED, "mp_coherence_f32: the lazy screen exists for 1024- to 4096-point transforms only%s");
+        return fail(MP_ERR_UNSUPPORTED, "mp_coherence_f32: the lazy screen exists for 1024- to 8192-point transforms only%s");
     if (reinterpret_cast<uintptr_t>(workspace) % 256) return fail(MP_ERR_WORKSPACE, "workspace not 256-byte aligned%s");
     if (workspace_bytes < mp_coherence_workspace_bytes(A, L)) return fail(MP_ERR_WORKSPACE, "workspace too small%s");
     hipStream_t st = static_cast<hipStream_t>(stream);
@@ -1995,8 +2028,7 @@ static int encode_impl(const float *signal, int64_t B, int64_t N, const float *d
             float *lbfloor = reinterpret_cast<float *>(w.pctl + 256 + 512 * 64 + ((size_t)B * (K - 1) + 2) * 128);
             if (mu) {   // the lazy screen's floor: where this run's maxima are expected to end (mppersist.inc)
                 // (rank K + K/16 + 1: now and then one event leaves two peaks; radius 1 + ceil(max(0, L - 512) / 256) blocks)
-                const int tuned = persist_radius.load(std::memory_order_relaxed);
-                const int radius = tuned > 0 ? tuned : tuned < 0 ? 0 : (int)(1 + std::max<int64_t>(0, (L - 512 + 255) / 256));
+                const int radius = lazy_radius_for(L);
                 if (g.NBLK <= FLOOR_WAVE_MAXBLK)
                     hipLaunchKernelGGL(persist_floor_wave_kernel, dim3((unsigned)B), dim3(64), 0, st, (const unsigned *)w.bsum, g.NBLK,
                                        K + K / 16 + 1, radius, lbfloor);
@@ -2040,6 +2072,13 @@ static int encode_impl(const float *signal, int64_t B, int64_t N, const float *d
     const bool naive = path == MP_PATH_NAIVE;
     const bool incremental = path == MP_PATH_INCREMENTAL;
     const int64_t cells = (int64_t)g.NBLK * (naive ? g.A : g.NAT);
+    // the lazy screen where the launch-per-step form has it (fft_iteration: the fused select with block summaries)
+    LazyArgs lz;
+    if (path == MP_PATH_FFT && coherence && !conv_model) {
+        lz.mu = coherence;
+        lz.margin = persist_margin.load(std::memory_order_relaxed);
+        lz.reuse = lazy_reuse_for(K);
+    }
     // the K steps; whatever it returns, the forked streams are joined back into the caller's below
     auto run_steps = [&]() -> int {
         for (int k = 0; k < K; ++k) {
@@ -2055,7 +2094,7 @@ static int encode_impl(const float *signal, int64_t B, int64_t N, const float *d
                 int rcq;
                 if (path == MP_PATH_FFT) {
                     if ((rcq = fft_iteration(gq, wq, dict_unit, K, k,
-                                             flags | (n_groups == 1 ? MP_FLAG_INTERNAL_ONE_STREAM : 0), oa, ol, og, rule, sq)))
+                                             flags | (n_groups == 1 ? MP_FLAG_INTERNAL_ONE_STREAM : 0), oa, ol, og, rule, sq, lz)))
                         return rcq;
                     continue;
                 }
@@ -2375,6 +2414,15 @@ int mp_persist_stats(uint64_t *out8 /* [16] */) {
         HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(g_persist_phase), zero, sizeof(zero)));
     }
     out8[14] = nine[8];   // screen tasks answered without a transform (lazy screen)
+    return MP_OK;
+}
+
+int mp_lazy_stats(uint64_t *out2 /* [2] */) {
+    if (!out2) return fail(MP_ERR_ARG, "mp_lazy_stats: null output%s");
+    const uint64_t zero[2] = {0, 0};
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpyFromSymbol(out2, HIP_SYMBOL(g_lazy_stats), sizeof(zero)));
+    HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(g_lazy_stats), zero, sizeof(zero)));
     return MP_OK;
 }
 

@@ -52,7 +52,7 @@ EXPORTS = (
     "mp_dictionary_update_f32", "mp_lcn_workspace_bytes", "mp_encode_lcn_f32", "mp_conv_model_backward_f32",
     "mp_stream_pair_ratio", "mp_init_streams", "mp_audit_read", "mp_dictionary_levels_host",
     "mp_dictionary_update_levels_f32", "mp_persist_stats", "mp_last_schedule", "mp_encode_lazy_f32",
-    "mp_coherence_f32", "mp_coherence_workspace_bytes",
+    "mp_coherence_f32", "mp_coherence_workspace_bytes", "mp_lazy_stats",
 )
 
 
@@ -174,6 +174,14 @@ def persist_stats():
                               for i, p in enumerate(("acquire", "scan", "chains", "event_window", "transform_stores"))}
     out["prescans"] = int(buf[15])
     return out
+
+
+def lazy_stats():
+    """mp_lazy_stats: dict(skipped, decided) -- (segment, tile) screens the launch-per-step lazy screen left out / decided on
+    since the last read (the persistent form counts its own in persist_stats()['skipped']).  Synchronises; resets."""
+    buf = (ctypes.c_uint64 * 2)()
+    _check(lib().mp_lazy_stats(buf), "mp_lazy_stats")
+    return dict(skipped=int(buf[0]), decided=int(buf[1]))
 
 
 def audit_read():

@@ -18,19 +18,35 @@ du = nat.unit_norm(torch.from_numpy(d).cuda())
 nat.encode(xd[:4], du, 2, path=nat.MP_PATH_FFT); torch.cuda.synchronize()
 M = 8192
 spectra_bytes = (A // 2 + 1) * 8.0 * M
-for name, flags, every in (("one stream, events around every launch", nat.MP_FLAG_NO_OVERLAP, 1),
-                           ("one stream", nat.MP_FLAG_NO_OVERLAP, 16),
-                           ("two sub-batches on forked streams (library default)", 0, 16)):
-    nat.profile_enable(every); nat.profile_read()
+t0 = time.perf_counter()
+mu = nat.coherence_table(du)
+torch.cuda.synchronize()
+print(f"coherence table (mp_coherence_f32, first call): {(time.perf_counter() - t0) * 1e3:.1f} ms", flush=True)
+t0 = time.perf_counter()
+mu = nat.coherence_table(du)
+torch.cuda.synchronize()
+print(f"coherence table (second call): {(time.perf_counter() - t0) * 1e3:.1f} ms", flush=True)
+ref = None
+for name, flags, every, co in (("one stream, events around every launch", nat.MP_FLAG_NO_OVERLAP, 1, False),
+                               ("one stream", nat.MP_FLAG_NO_OVERLAP, 16, False),
+                               ("one stream, lazy screen", nat.MP_FLAG_NO_OVERLAP, 16, mu),
+                               ("one stream, lazy screen, events around every launch", nat.MP_FLAG_NO_OVERLAP, 1, mu),
+                               ("library default (table from the cache)", 0, 0, None),
+                               ("library default again", 0, 0, None)):
+    nat.profile_enable(every); nat.profile_read(); nat.lazy_stats()
     t0 = time.perf_counter()
-    atom, lag, gain, res = nat.encode(xd, du, K, path=nat.MP_PATH_FFT, flags=flags)
+    atom, lag, gain, res = nat.encode(xd, du, K, path=nat.MP_PATH_FFT, flags=flags, coherence=co)
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     p = nat.profile_read()
+    ls = nat.lazy_stats()
+    if ref is None:
+        ref = (atom, lag, gain, res)
+    print(f"   lazy screen: {ls}; identical to the first run: {all(torch.equal(a, b) for a, b in zip(ref, (atom, lag, gain, res)))}", flush=True)
     print(f"c4 full, {name}: B{B} K{K}: {dt:.3f} s -> {B * K / dt:.0f} seg-it/s; overflow segments: "
           f"{int(torch.isnan(gain).any(dim=1).sum())}", flush=True)
     print("  ", {k: (round(v[0] / max(v[1], 1), 3), v[1]) for k, v in p.items()}, "ms avg, spans", flush=True)
-    if flags:
+    if flags and p['corr_inc'][1]:
         inc = p['corr_inc'][0] / p['corr_inc'][1] * 1e-3
         print(f"   screen: algorithmic spectra per incremental launch {B * spectra_bytes / 1e9:.2f} GB -> "
               f"{B * spectra_bytes / inc / 1e12:.2f} TB/s", flush=True)

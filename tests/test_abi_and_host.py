@@ -238,3 +238,69 @@ def test_oracle_under_host_sanitizers():
                          env=env, capture_output=True, text=True, timeout=900, cwd=REPO)
     assert run.returncode == 0, run.stdout[-3000:] + run.stderr[-3000:]
     assert "passed" in run.stdout and "AddressSanitizer" not in run.stderr and "runtime error" not in run.stderr
+
+
+# ---- lazy event lists (mpcore/matchingpursuit.py::EventList / _EventStore: the drop-in surface's return structures) ----
+def test_event_lists_are_lazy_and_equal_to_the_eager_structures():
+    """sparse_code's `instances` / flattened list hold ranges of the packed arrays and build the reference's tuples
+    (modules/matchingpursuit.py:305-321: (atom, batch, lag[1,1], gain * d[atom] [1,1,L])) only when looked at; what
+    they build equals the eager construction -- keys in first-selection order (steps outer, batch inner), each list in
+    (step, batch) order, flatten_atom_dict grouped by atom (:61-65)."""
+    from collections import defaultdict
+    import mpcore.matchingpursuit as mpm
+    rng = np.random.default_rng(3)
+    B, K, A, L = 5, 7, 6, 4
+    atom = torch.from_numpy(rng.integers(0, A, size=(B, K)))
+    lag = torch.from_numpy(rng.integers(0, 100, size=(B, K)))
+    gain = torch.from_numpy(rng.standard_normal((B, K)).astype(np.float32))
+    du = torch.from_numpy(rng.standard_normal((A, L)).astype(np.float32))
+    want = defaultdict(list)
+    for k in range(K):
+        for b in range(B):
+            a = int(atom[b, k])
+            want[a].append((a, b, int(lag[b, k]), du[a] * gain[b, k]))
+    store = mpm._EventStore(atom, lag, gain, du, torch.device("cpu"), A)
+    inst = store.instances()
+    assert isinstance(inst, defaultdict) and list(inst.keys()) == list(want.keys())
+    assert all(isinstance(v, list) and v._store is store for v in inst.values())      # nothing built yet
+    assert [len(v) for v in inst.values()] == [len(v) for v in want.values()] and store._tuples is None
+    flat = mpm.flatten_atom_dict(inst)
+    assert flat._store is store and len(flat) == B * K and store._tuples is None       # still lazy, as a range of the store
+    pk = flat.packed
+    assert store._tuples is None and pk["atom"].tolist() == [e[0] for v in want.values() for e in v]
+    assert pk["batch"].tolist() == [e[1] for v in want.values() for e in v]
+    assert pk["lag"].tolist() == [e[2] for v in want.values() for e in v]
+    # looking at one event builds them
+    ev = flat[0]
+    assert store._tuples is not None and flat._store is None
+    assert isinstance(ev, tuple) and isinstance(ev[0], int) and isinstance(ev[1], int)
+    assert ev[2].shape == (1, 1) and ev[2].dtype == torch.int64 and ev[3].shape == (1, 1, L)
+    eager = [e for v in want.values() for e in v]
+    assert len(list(flat)) == len(eager)
+    for got, w in zip(flat, eager):
+        assert got[0] == w[0] and got[1] == w[1] and int(got[2]) == w[2] and torch.equal(got[3].view(L), w[3])
+    for a, v in inst.items():
+        assert [(e[0], e[1], int(e[2])) for e in v] == [(e[0], e[1], e[2]) for e in want[a]]
+    # list behaviour on a fresh, unmaterialised list: concatenation either way, comparison, copy, membership, slices
+    flat2 = store.flat()
+    assert ([1] + flat2)[0] == 1 and len([1] + flat2) == B * K + 1
+    flat3 = store.flat()
+    assert len(flat3 + [2]) == B * K + 1 and (flat3 + [2])[-1] == 2 and flat3.packed is not None
+    assert len(store.flat()[2:5]) == 3 and list(reversed(store.flat()))[0][1] == eager[-1][1]
+    assert store.flat().copy().__class__ is list or len(store.flat().copy()) == B * K
+    assert bool(store.flat()) and not bool(mpm.EventList())
+    # a mutated list no longer carries packed arrays (they would not describe it)
+    flat4 = store.flat()
+    flat4.append(eager[0])
+    assert flat4.packed is None and len(flat4) == B * K + 1
+    flat5 = store.flat()
+    del flat5[0]
+    assert flat5.packed is None and len(flat5) == B * K - 1
+    # a dict the caller changed is flattened the general way
+    inst2 = store.instances()
+    first = next(iter(inst2))
+    inst2[first] = list(inst2[first])[:1]
+    assert len(mpm.flatten_atom_dict(inst2)) == B * K - len(want[first]) + 1
+    # an empty encode
+    empty = mpm._EventStore(atom[:, :0], lag[:, :0], gain[:, :0], du, torch.device("cpu"), A)
+    assert len(empty.instances()) == 0 and len(empty.flat()) == 0 and list(empty.flat()) == []

@@ -897,6 +897,43 @@ def test_lazy_screen_is_bit_identical_to_the_oracle(oracle):
         nat.tune(nat.MP_TUNE_LAZY_MARGIN, 0.7)
 
 
+def test_lazy_screen_of_the_launch_per_step_form_is_bit_identical_to_the_oracle(oracle):
+    """Shapes the persistent form does not take (more than 16384 cells per segment; 8192-point transforms as BASELINE
+    configs[3] has them) run launch per step with the fused whole-cell select -- and, given the coherence table, with the
+    lazy screen in THAT form: the select leaves a tile mask, the next screen launch's workgroups of those tiles leave at
+    once (csrc/mpfft.inc: fft_select_fused_kernel / fft_screen_kernel).  Same events as the oracle, bit for bit, at any
+    margin; tiles really are skipped; without the table nothing is."""
+    try:
+        for A, L, N, B, K, flags in ((512, 128, 70400, 6, 24, 0), (160, 2048, 300000, 2, 6, nat.MP_FLAG_FFT_FUSED)):
+            d = synth.make_dictionary(A, L, seed=31 + A)
+            du_np = oracle.unit_norm(d)
+            du = torch.from_numpy(du_np).to(DEV)
+            x_host = synth.make_segments(B, N, d, n_events=3 * K, seed=17 + B)
+            want = oracle.encode(x_host, du_np, K)
+            x = torch.from_numpy(x_host).to(DEV)
+            assert nat.lib().mp_coherence_workspace_bytes(A, L) > 0
+            mu = nat.coherence_table(du)
+            nat.lazy_stats()
+            plain = nat.encode(x, du, K, path=nat.MP_PATH_FFT, flags=flags, coherence=False)
+            torch.cuda.synchronize()
+            assert nat.last_schedule() == 1 and nat.lazy_stats()["decided"] == 0
+            for name, t in zip(("atom", "lag", "gain", "residual"), plain):
+                assert np.array_equal(t.cpu().numpy(), want[name]), (A, L, "plain", name)
+            for margin in (1.0, 0.7, 0.3):
+                nat.tune(nat.MP_TUNE_LAZY_MARGIN, margin)
+                a, l, g, r = nat.encode(x, du, K, path=nat.MP_PATH_FFT, flags=flags, coherence=mu)
+                torch.cuda.synchronize()
+                st = nat.lazy_stats()
+                assert nat.last_schedule() == 1 and st["decided"] == B * (K - 2) * ((A + 31) // 32), (A, L, margin, st)
+                assert st["skipped"] > st["decided"] // 20, (A, L, margin, st)
+                keep = ~torch.isnan(g).any(dim=1).cpu().numpy()   # (a marked segment is re-encoded by the caller)
+                assert keep.sum() >= B - 1, (A, L, margin)
+                for name, t in zip(("atom", "lag", "gain", "residual"), (a, l, g, r)):
+                    assert np.array_equal(t.cpu().numpy()[keep], want[name][keep]), (A, L, margin, name)
+    finally:
+        nat.tune(nat.MP_TUNE_LAZY_MARGIN, 0.7)
+
+
 def test_persistent_form_with_scarce_and_odd_worker_counts(oracle):
     """The queue must not depend on how many workgroups serve it: one select worker for fifty segments, three screen
     workers in all, more select workers than segments, a grid larger than what is resident -- all bit-identical to the
@@ -992,7 +1029,9 @@ def test_plan_replayed_after_an_in_place_dictionary_update(oracle):
     A, L, N, B, K = 64, 256, 6000, 40, 12
     d1, d2 = synth.make_dictionary(A, L, seed=161), synth.make_dictionary(A, L, seed=162)
     du1, du2 = oracle.unit_norm(d1), oracle.unit_norm(d2)
-    x_host = synth.make_segments(B, N, d1, n_events=10, seed=163) + synth.make_segments(B, N, d2, n_events=10, seed=164)
+    # (each dictionary has more planted events in the mix than the run has steps: the lazy screen's floor -- the
+    #  (K + K/16 + 1)-th peak, DESIGN.md 4c -- then sits among the strong events and tiles do get skipped)
+    x_host = synth.make_segments(B, N, d1, n_events=24, seed=163) + synth.make_segments(B, N, d2, n_events=24, seed=164)
     x = torch.from_numpy(x_host).to(DEV)
     du = torch.from_numpy(du1).to(DEV)
     plan = nat.EncodePlan(B, N, du, K)
