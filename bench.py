@@ -55,30 +55,59 @@ PEAK_HBM_GBS = 8000.0         # MI355X HBM3E peak (MI355X_MICROARCH.md)
 # (= 64 flop / clk / SIMD, the 157.3 TFLOP/s vector peak of MI355X_MICROARCH.md)
 N_SIMD, PEAK_CLOCK_HZ, CYCLES_PER_WAVE_INSTR = 1024, 2.4e9, 4
 PEAK_VALU_GINSTR = N_SIMD * PEAK_CLOCK_HZ / CYCLES_PER_WAVE_INSTR / 1e9   # 614.4 G wave-instructions/s
-VALU_PER_THREAD_TRANSFORM = 410  # VALU instructions of one 16-point thread-transform of the screen (counted in the ISA)
+# VALU instructions one thread spends per 16-point share of one M-point transform in the screen's loop over atom pairs
+# (spectrum product, transform, running maxima), per kernel: READ FROM THE BUILT CODE OBJECT at run time
+# (scripts/kernel_resources.py::screen_pair_loop disassembles libmpcore.so and counts the loop body); this table is the
+# fallback where the LLVM tools are missing, and tests/test_abi_and_host.py holds it equal to the code object.
+VALU_PER_THREAD_TRANSFORM = {("persistent", 11): 408, ("screen", 11): 441, ("screen", 13): 536}
+_valu_cache = {}
+
+
+def valu_per_thread_transform(kind, log_m):
+    """-> (VALU instructions per thread and transform, where the number comes from)."""
+    key = (kind, log_m)
+    if key not in _valu_cache:
+        try:
+            import importlib.util
+            spec = importlib.util.spec_from_file_location("kernel_resources", os.path.join(REPO, "scripts", "kernel_resources.py"))
+            kr = importlib.util.module_from_spec(spec)
+            spec.loader.exec_module(kr)
+            _valu_cache[key] = (kr.screen_pair_loop(kind, log_m)["valu"], "code object")
+        except Exception as e:  # noqa: BLE001  (no llvm-objdump here: the table, checked against the code object by the CPU tests)
+            _valu_cache[key] = (VALU_PER_THREAD_TRANSFORM[key], f"table ({type(e).__name__})")
+    return _valu_cache[key]
+
+
 PATHS = {"fft": nat.MP_PATH_FFT, "incremental": nat.MP_PATH_INCREMENTAL, "direct": nat.MP_PATH_DIRECT}
 
 
-def fft_geometry():
-    """(M, V): transform size and valid lags per transform, as csrc/mpfft.inc::make_fft_geom."""
-    M = 256
-    while M < 3 * L + 190:
-        M *= 2
-    return M, (M - L + 1) // 64 * 64
+class Shape:
+    """One workload: dictionary A x L, B segments of N samples, K steps; M = transform size, V = valid lags per
+    transform (csrc/mpfft.inc::make_fft_geom)."""
+
+    def __init__(self, A, L, N, B, K, name):
+        self.A, self.L, self.N, self.B, self.K, self.name = A, L, N, B, K, name
+        M = 256
+        while M < 3 * L + 190:
+            M *= 2
+        self.M, self.V, self.log_m = M, (M - L + 1) // 64 * 64, M.bit_length() - 1
+        self.nw_full = -(-N // self.V)
 
 
-def algorithmic_bytes_fft(n_segments, steps_k):
+HEAD = Shape(A, L, N, B_PER_GPU, K_ITERS, "BASELINE configs[1] per GPU: 512x512 dictionary, 64 x 32768-sample segments, K=64")
+C3 = Shape(4096, 2048, 131072, 128, 256, "BASELINE configs[3] at full size: 4096x2048 dictionary, 128 x 131072-sample segments, K=256")
+
+
+def algorithmic_bytes_fft(sh):
     """Bytes the FFT screen kernel must read per encode, by its own algorithm: per (segment, window)
     the window spectrum (8 M bytes) and one pair spectrum per two atoms (A/2 * 8 M bytes), plus one
     8-byte key and 4-byte bound written per cell.  Full pass: ceil(N / V) windows per segment;
     every later step: one window per segment."""
-    M, V = fft_geometry()
-    per_window = 8.0 * M * (A // 2 + 1)
-    nw_full = -(-N // V)
-    cells_full = (N // 64) * (A // 32) * 12.0
-    cells_inc = ((2 * L - 2) // 64 + 2) * (A // 32) * 12.0
-    full = n_segments * (nw_full * per_window + cells_full)
-    inc = n_segments * (steps_k - 1) * (per_window + cells_inc)
+    per_window = 8.0 * sh.M * (sh.A // 2 + 1)
+    cells_full = (sh.N // 64) * (sh.A // 32) * 12.0
+    cells_inc = ((2 * sh.L - 2) // 64 + 2) * (sh.A // 32) * 12.0
+    full = sh.B * (sh.nw_full * per_window + cells_full)
+    inc = sh.B * (sh.K - 1) * (per_window + cells_inc)
     return full + inc, full, inc
 
 
@@ -97,16 +126,22 @@ def algorithmic_flops(lag, path):
     return full + inc, full, inc
 
 
-def timed_encodes(x, du, steps, warmup, path, flags, group):
+def timed_encodes(x, du, steps, warmup, path, flags, group, n_iters=K_ITERS, before_each=None, coherence=None):
+    """`before_each`: called ahead of every encode, timed ones included (e.g. nat.clear_caches: a new dictionary every call)."""
     for _ in range(warmup):
-        out = nat.encode(x, du, K_ITERS, path=path, flags=flags, want_residual=True)
+        if before_each:
+            before_each()
+        out = nat.encode(x, du, n_iters, path=path, flags=flags, want_residual=True, coherence=coherence)
     torch.cuda.synchronize()
     nat.profile_read()  # drop warm-up spans
+    nat.lazy_stats()
     mpdist.barrier(group)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(steps):
-        out = nat.encode(x, du, K_ITERS, path=path, flags=flags, want_residual=True)
+        if before_each:
+            before_each()
+        out = nat.encode(x, du, n_iters, path=path, flags=flags, want_residual=True, coherence=coherence)
     torch.cuda.synchronize()
     mpdist.barrier(group)
     dt = time.perf_counter() - t0
@@ -123,7 +158,14 @@ def pmc_traffic(kernel="correlate"):
     import glob
     files = sorted(glob.glob(os.path.join(REPO, "profiles", "r*_summary.json")))
     # the pass that profiled THIS kernel's schedule first (the persistent passes also contain the step-0 screen launches)
-    own = {"fft_persistent": "_persist_", "fft_screen": "_fft_", "correlate": "_mfma_"}.get(kernel, "")
+    own = {"fft_persistent": "_persist_", "fft_screen": "_fft_", "correlate": "_mfma_", "c3_fft_screen": "_c4_"}.get(kernel, "")
+    if kernel == "c3_fft_screen":   # the configs[3]-shape pass (scripts/c4_traffic.py under rocprofv3): its own key
+        for f in reversed([f for f in files if own in os.path.basename(f)]):
+            try:
+                return json.load(open(f)).get("hbm_traffic_bytes_per_incremental_launch_fft_screen_kernel")
+            except (OSError, ValueError):
+                continue
+        return None
     files = [f for f in files if own not in os.path.basename(f)] + [f for f in files if own in os.path.basename(f)]
     for f in reversed(files):
         try:
@@ -139,7 +181,7 @@ def pmc_traffic(kernel="correlate"):
 PROF_EVERY = 16  # hipEvent spans around the kernels of iterations 0, 16, 32, 48 of every timed encode
 
 
-def launch_times(prof, steps):
+def launch_times(prof, steps, n_iters=K_ITERS):
     """Sampled HIP-event spans -> (seconds all launches of the dominant kernel took, per-kind figures).
     An event between two kernels idles the GPU for ~10 us (scripts/prof_overhead.py: 7.5 vs 6.0 ms per
     encode with spans around every launch), so only every PROF_EVERY-th iteration of the timed region
@@ -152,8 +194,8 @@ def launch_times(prof, steps):
     # the FFT schedule splits the batch into sub-batches on forked streams (one launch per sub-batch and
     # step): the sampled full passes tell how many
     groups = max(1, n_full // steps) if n_inc else 1
-    full_launches = steps * groups if n_inc else steps * K_ITERS   # MP_PATH_DIRECT: every launch is a full pass
-    inc_launches = steps * (K_ITERS - 1) * groups if n_inc else 0
+    full_launches = steps * groups if n_inc else steps * n_iters   # MP_PATH_DIRECT: every launch is a full pass
+    inc_launches = steps * (n_iters - 1) * groups if n_inc else 0
     avg_full = ms_full / max(n_full, 1)
     avg_inc = ms_inc / max(n_inc, 1)
     sec = (avg_full * full_launches + avg_inc * inc_launches) * 1e-3
@@ -167,36 +209,42 @@ def launch_times(prof, steps):
     }
 
 
-def roofline_fft(prof, n_segments, steps):
-    """Roofline of fft_screen_kernel on the resource that binds it: packed-fp32 VALU issue.
+def roofline_fft(prof, sh, steps, lazy=None):
+    """Roofline of fft_screen_kernel<log2 M> on the resource that binds it: packed-fp32 VALU issue.
 
-    achieved = ALGORITHMIC wave-instructions (transforms x waves per transform x 410 VALU instructions per
-    16-point thread-transform, counted in the ISA; rocprof's SQ_INSTS_VALU for an incremental launch is 9 % above
-    this count: address arithmetic and the cell-maximum epilogue) / launch durations; peak = 1024 SIMDs x 2.4 GHz / 4
-    cycles per wave64 instruction.  HBM is reported beside it from the committed PMC passes: `traffic` bytes per
-    launch / average launch duration = hbm_gbs_measured."""
-    lt = launch_times(prof, steps)
+    achieved = ALGORITHMIC wave-instructions (transforms RUN x waves per transform x the VALU instructions of one
+    16-point thread-transform, read from the kernel's pair loop in the built code object) / launch durations; peak = 1024
+    SIMDs x 2.4 GHz / 4 cycles per wave64 instruction.  With the lazy screen (`lazy` = mp_lazy_stats of the timed region)
+    the (segment, tile) screens the select left out are not counted: they ran no transform.  HBM is reported beside it
+    from the committed PMC passes: `traffic` bytes per launch / average launch duration = hbm_gbs_measured."""
+    lt = launch_times(prof, steps, sh.K)
     if lt is None:
         return None
     sec, per_kind = lt
-    M, V = fft_geometry()
-    transforms = n_segments * (A // 2) * (-(-N // V) + K_ITERS - 1) * steps
-    wave_instr = transforms * (M // 16 // 64) * VALU_PER_THREAD_TRANSFORM
+    valu, valu_src = valu_per_thread_transform("screen", sh.log_m)
+    all_transforms = sh.B * (sh.A // 2) * (sh.nw_full + sh.K - 1) * steps
+    skipped_transforms = 16 * lazy["skipped"] if lazy else 0     # a tile = 16 atom pairs, one window per incremental launch
+    transforms = all_transforms - skipped_transforms
+    waves = sh.M // 16 // 64
+    wave_instr = transforms * waves * valu
     achieved = wave_instr / sec / 1e9
-    traffic = pmc_traffic("fft_screen")
+    traffic = pmc_traffic("fft_screen" if sh is HEAD else "c3_fft_screen")
     out = {
         "bound": "valu", "achieved": round(achieved, 1), "peak": round(PEAK_VALU_GINSTR, 1),
         "unit": "G wave64-instructions/s (packed fp32 issue)",
         "frac": round(achieved / PEAK_VALU_GINSTR, 4), "traffic": traffic,
-        "kernel": "fft_screen_kernel<11> (radix-16 Stockham, packed fp32)",
+        "kernel": f"fft_screen_kernel<{sh.log_m}> (radix-16 Stockham, packed fp32)",
+        "valu_per_thread_transform": valu, "valu_count_from": valu_src,
     }
     out.update(per_kind)
     avg_s = sec / per_kind["launches"]
     if traffic is not None:
-        out["hbm_gbs_measured"] = round(traffic / avg_s / 1e9, 1)
-        out["frac_hbm"] = round(traffic / avg_s / 1e9 / PEAK_HBM_GBS, 4)
-    total, full, inc = algorithmic_bytes_fft(n_segments, K_ITERS)
-    survey_bytes = (8.0 * ((N + L) // 2 + 1) * (A + 1) + 8.0 * N) * n_segments * K_ITERS  # SURVEY.md 8(d)
+        # (the PMC passes measure an incremental launch; the full pass is one launch in K)
+        inc_s = per_kind["incremental_avg_ms"] * 1e-3 if per_kind["incremental_launches"] else avg_s
+        out["hbm_gbs_measured"] = round(traffic / inc_s / 1e9, 1)
+        out["frac_hbm"] = round(traffic / inc_s / 1e9 / PEAK_HBM_GBS, 4)
+    total, full, inc = algorithmic_bytes_fft(sh)
+    survey_bytes = (8.0 * ((sh.N + sh.L) // 2 + 1) * (sh.A + 1) + 8.0 * sh.N) * sh.B * sh.K  # SURVEY.md 8(d)
     out.update({
         "other_kernels_avg_ms_per_iteration": round(prof["select"][0] / max(per_kind["timed_with_events"]["full_pass"]
                                                     + per_kind["timed_with_events"]["incremental"], 1), 5),
@@ -207,20 +255,27 @@ def roofline_fft(prof, n_segments, steps):
         "spectra_streamed_gbs": round(total * steps / sec / 1e9, 1),
         "survey_8d_equivalent_gbs": round(survey_bytes * steps / sec / 1e9, 1),
         "note": "HBM does not bind this kernel and the north-star's >= 70 % HBM target does not apply to it: the "
-                "spectra it streams (spectra_streamed_*) are L2 / Infinity-Cache hits (4 MiB of pair spectra shared "
-                "by all segments); fabric traffic is `traffic` bytes per launch (FETCH_SIZE x 2 + WRITE_SIZE, "
+                "spectra it streams (spectra_streamed_*) are L2 / Infinity-Cache hits (pair spectra shared by all "
+                "segments); fabric traffic is `traffic` bytes per launch (FETCH_SIZE x 2 + WRITE_SIZE, "
                 "separate rocprofv3 --pmc passes, profiles/) = hbm_gbs_measured.  By SURVEY.md 8(d)'s own per-unit "
                 "bytes (the reference's full-length transform) the run would exceed HBM peak "
                 "(survey_8d_equivalent_gbs): the screen does not do that work, it screens one window of dirty lags "
                 "and refines exactly (DESIGN.md 4b, 6).",
     })
+    if lazy:
+        out["lazy_screen"] = {
+            "tile_screens_without_it": lazy["decided"], "tile_screens_skipped": lazy["skipped"],
+            "transforms_without_it": all_transforms, "transforms_run": transforms,
+            "selects_that_decided_nothing": {k: lazy[k] for k in ("off_static", "off_contenders", "off_no_floor", "off_no_bound")},
+            "contender_cells_refined": lazy["contender_cells"],
+        }
     return out
 
 
 WARMUP_STEPS = 2   # (main() stores --warmup here: the lazy screen's note says where the table was computed)
 
 
-def roofline_persistent(prof, n_segments, steps):
+def roofline_persistent(prof, sh, steps):
     """Roofline of fft_persistent_kernel (steps 1 .. K-1 of the whole batch in one launch) on packed-fp32 VALU issue.
 
     achieved = the screens' ALGORITHMIC wave-instructions per launch (segments x A/2 pair transforms x (K-1) steps x
@@ -232,17 +287,18 @@ def roofline_persistent(prof, n_segments, steps):
     ms_p, n_p = prof["corr_inc"]
     if n_p == 0:
         return None
-    M, V = fft_geometry()
-    waves = M // 16 // 64
+    waves = sh.M // 16 // 64
     pst = nat.persist_stats()   # (of the last launch)
-    all_transforms = n_segments * (A // 2) * (K_ITERS - 1)
+    all_transforms = sh.B * (sh.A // 2) * (sh.K - 1)
     pairs_per_task = 8          # two slots of four atom pairs (csrc/mppersist.inc, M = 2048)
     transforms = pst["tasks"] * pairs_per_task   # the ones RUN: the lazy screen answers the rest from widened bounds
-    wave_instr = transforms * waves * VALU_PER_THREAD_TRANSFORM
+    valu, valu_src = valu_per_thread_transform("persistent", sh.log_m)
+    valu0, _ = valu_per_thread_transform("screen", sh.log_m)     # (step 0's full pass is fft_screen_kernel)
+    wave_instr = transforms * waves * valu
     avg_s = ms_p / n_p * 1e-3
     achieved = wave_instr / avg_s / 1e9
     traffic = pmc_traffic("fft_persistent")
-    t0 = n_segments * (A // 2) * -(-N // V)
+    t0 = sh.B * (sh.A // 2) * sh.nw_full
     out = {
         "bound": "valu", "achieved": round(achieved, 1), "peak": round(PEAK_VALU_GINSTR, 1),
         "unit": "G wave64-instructions/s (packed fp32 issue)",
@@ -254,8 +310,9 @@ def roofline_persistent(prof, n_segments, steps):
         "algorithmic_wave_instructions_per_launch": wave_instr, "transforms_per_launch": transforms,
         "valu_floor_ms_per_launch": round(wave_instr / (PEAK_VALU_GINSTR * 1e9) * 1e3, 5),
         "step0_screen_avg_ms": round(ms_full / max(n_full, 1), 5),
-        "step0_screen_frac_valu": round(t0 * waves * VALU_PER_THREAD_TRANSFORM / (ms_full / max(n_full, 1) * 1e-3) / 1e9
+        "step0_screen_frac_valu": round(t0 * waves * valu0 / (ms_full / max(n_full, 1) * 1e-3) / 1e9
                                         / PEAK_VALU_GINSTR, 4) if n_full else None,
+        "valu_per_thread_transform": valu, "valu_count_from": valu_src,
         "other_kernels_avg_ms_per_encode": round(prof["select"][0] / max(n_p, 1), 5),
     }
     if traffic is not None:
@@ -269,6 +326,8 @@ def roofline_persistent(prof, n_segments, steps):
                 "encode against the same tensor): " +
                 ("during warm-up" if WARMUP_STEPS >= 1 else "inside the timed region, in its first step"),
     }
+    ls = nat.lazy_stats()
+    out["contender_quarters_per_select"] = round(ls["contender_quarters"] / max(pst["selects"], 1) / max(steps, 1), 3)
     out["inside_the_launch"] = {
         "screen_task_us": round(pst["task_ticks"] / max(pst["tasks"], 1) / 100.0, 2), "tasks": pst["tasks"],
         "select_us": round(pst["select_ticks"] / max(pst["selects"], 1) / 100.0, 2), "selects": pst["selects"],
@@ -342,6 +401,164 @@ def cpu_baseline(d, x_host, gpu_sample):
     }, parity
 
 
+def cpu_baseline_torch(d, x_host, gpu_sample):
+    """SURVEY.md 8(d)'s second CPU baseline: the reference's loop in the torch CPU operators it calls itself (F.conv1d =
+    oneDNN, torch.max; oracle/mp_oracle_torch.py, test infrastructure) at all of this host's cores and at 8 threads (the
+    build container's count), on the first 8 segments x 4 iterations of the same workload."""
+    sys.path.insert(0, os.path.join(REPO, "oracle"))
+    import mp_oracle
+    import mp_oracle_torch as mot
+    du = mot.unit_norm(d).numpy()
+    cores = mp_oracle.cpu_share()
+    b_s, k_s = min(8, x_host.shape[0]), 4
+    atom, lag, gain = gpu_sample
+    out = {}
+    for label, threads in (("all_cores", cores), ("8_threads", min(8, cores))):
+        rate, dt, res = mot.timed_encode(x_host[:b_s], du, k_s, threads)
+        out[label] = {"value": round(rate, 3), "unit": "segment-iterations/s", "cores": threads, "kind": "port",
+                      "sample": f"{b_s} of the 64 segments x the first {k_s} of 64 iterations, F.conv1d + torch.max on "
+                                f"{threads} threads, {dt:.1f} s",
+                      "picks_equal_gpu": bool(np.array_equal(res["atom"], atom[:b_s, :k_s]) and
+                                              np.array_equal(res["lag"], lag[:b_s, :k_s]))}
+    return out
+
+
+def _rate(fn, steps):
+    """Median-free plain timing of `steps` synchronised calls after one warm-up -> (seconds per call, last result)."""
+    out = fn()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        out = fn()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / steps, out
+
+
+def non_ideal_variants(x, du, d, head_out, steps, group):
+    """What the headline does not time: a new dictionary every call, the checked product entry
+    point, the reference-shaped surface, and signals that are NOT sparse in the dictionary."""
+    import mpcore
+    from mpcore import encode_packed
+    import mpcore.matchingpursuit as mpm
+    B, K = HEAD.B, HEAD.K
+    seg = B * K
+    v = {}
+    nat.profile_enable(0)
+    # (b) the coherence table never reused: every call sees a dictionary it has not seen (clear_caches before each encode;
+    #     at this batch size one call pays for the table -- mp_coherence_f32 runs inside every timed call)
+    dt, out, _ = timed_encodes(x, du, steps, 1, nat.MP_PATH_FFT, 0, group, before_each=nat.clear_caches)
+    v["fft_new_dictionary_every_call"] = {
+        "value": round(seg * steps / dt, 2), "unit": "segment-iterations/s", "ms_per_step": round(dt / steps * 1e3, 4), "steps": steps,
+        "bit_identical_to_headline": bool(all(torch.equal(p, q) for p, q in zip(out, head_out))),
+        "note": "nat.clear_caches() ahead of every encode: the dictionary's coherence table (0.45 ms) is rebuilt inside each call"}
+    # (c) the product's checked default (what sparse_code runs): unit_norm of the RAW dictionary on every call, the encode,
+    #     the NaN scan of the marks with its host synchronisation, re-encodes of marked segments (none here)
+    d_raw = torch.from_numpy(d).to(x.device)
+    sec, pk = _rate(lambda: encode_packed(x, d_raw, K), steps)
+    v["product_default_checked"] = {
+        "value": round(seg / sec, 2), "unit": "segment-iterations/s", "ms_per_step": round(sec * 1e3, 4), "steps": steps,
+        "bit_identical_to_headline": bool(torch.equal(pk["atom"], head_out[0]) and torch.equal(pk["gain"], head_out[2])),
+        "note": "mpcore.encode_packed(signal, raw dictionary, K): unit_norm + encode_checked (one host sync, NaN scan)"}
+    # ... and the reference's own call surface: sparse_code(flatten=True) + scatter_segments(shape, events), as
+    #     modules/multibanddict.py:239-266 uses it (event tuples are built only if somebody looks at them: EventList)
+    x3 = x[:, None, :]
+
+    def surface():
+        ev, scatter = mpm.sparse_code(x3, d_raw, n_steps=K, flatten=True)
+        return scatter(x3.shape, ev)
+    sec_s, _ = _rate(surface, steps)
+    sec_i, inst = _rate(lambda: mpm.sparse_code(x3, d_raw, n_steps=K), steps)
+    t0 = time.perf_counter()
+    n_ev = sum(len(list(vv)) for vv in inst[0].values())     # (looking at every event: the tuples get built)
+    dt_tuples = time.perf_counter() - t0
+    v["sparse_code_surface"] = {
+        "value": round(seg / sec_s, 2), "unit": "segment-iterations/s", "ms_per_step": round(sec_s * 1e3, 4), "steps": steps,
+        "ms_sparse_code_dict_of_events": round(sec_i * 1e3, 4), "ms_materialising_all_event_tuples": round(dt_tuples * 1e3, 3),
+        "events": n_ev,
+        "note": "sparse_code(signal[B,1,N], d, n_steps, flatten=True) + scatter_segments(shape, events) through mpcore's "
+                "mirror of modules.matchingpursuit; ratio to product_default_checked = the surface's own cost"}
+    # (d) signals that are not sparse in the dictionary: no planted atoms at all (harmonic bed + noise), and a mix -- half
+    #     as many planted atoms as steps -- whose maxima collapse to the bed's level mid-run.  Raw pass first (marks = NaN
+    #     gains counted), then the checked entry point whose retries the rate includes.
+    for name, n_events in (("unplanted_signal", 0), ("half_planted_signal", K // 2)):
+        xs = torch.from_numpy(synth.make_segments(B, HEAD.N, d, n_events=n_events, seed=2002)).to(x.device)
+        nat.clear_caches()
+        for _ in range(2):
+            raw = nat.encode(xs, du, K, path=nat.MP_PATH_FFT)
+        torch.cuda.synchronize()
+        nat.lazy_stats()
+        raw = nat.encode(xs, du, K, path=nat.MP_PATH_FFT)
+        torch.cuda.synchronize()
+        pst, ls = nat.persist_stats(), nat.lazy_stats()
+        marked = int(torch.isnan(raw[2]).any(dim=1).sum())
+        sec_raw, _ = _rate(lambda: nat.encode(xs, du, K, path=nat.MP_PATH_FFT), steps)
+        sec_chk, chk = _rate(lambda: nat.encode_checked(xs, du, K), steps)
+        inc = nat.encode(xs, du, K, path=nat.MP_PATH_INCREMENTAL)
+        torch.cuda.synchronize()
+        rdb = 20 * torch.log10(chk[3].norm(dim=-1) / xs.norm(dim=-1))
+        v[name] = {
+            "value": round(seg / sec_chk, 2), "unit": "segment-iterations/s", "ms_per_step": round(sec_chk * 1e3, 4), "steps": steps,
+            "planted_events_per_segment": n_events,
+            "unchecked_encode_ms": round(sec_raw * 1e3, 4), "segments_marked_by_the_first_pass": marked,
+            "share_of_time_in_retries": round(max(0.0, 1.0 - sec_raw / sec_chk), 4),
+            "contender_quarters_per_select": round(ls["contender_quarters"] / max(pst["selects"], 1), 3),
+            "screen_tasks_skipped_by_the_lazy_screen": pst["skipped"], "screen_tasks_run": pst["tasks"],
+            "identical_to_incremental_schedule": bool(all(torch.equal(p, q) for p, q in zip(chk[:3], inc[:3]))),
+            "residual_db_mean": round(float(rdb.mean()), 3),
+            "note": "encode_checked (the product default): marked segments are re-encoded without the lazy screen, then on "
+                    "the incremental schedule; `value` includes those retries"}
+    nat.profile_enable(PROF_EVERY)
+    return v
+
+
+def configs3_variant(dev):
+    """BASELINE configs[3] at full size on the library default (FFT screen launch per step, fused whole-cell select with
+    block summaries, lazy screen by tile mask): one warm-up encode (which also builds the dictionary's coherence table),
+    two timed ones; roofline of fft_screen_kernel<13> from HIP events inside the timed region."""
+    sh = C3
+    t0 = time.perf_counter()
+    d = synth.make_dictionary(sh.A, sh.L, seed=4000)
+    x = torch.empty(sh.B, sh.N, device=dev)
+    for b0 in range(0, sh.B, 32):   # SURVEY.md 8(d): E = 3 K planted events per segment
+        x[b0:b0 + 32] = torch.from_numpy(synth.make_segments(32, sh.N, d, n_events=3 * sh.K, seed=4001, first_index=b0)).to(dev)
+    du = nat.unit_norm(torch.from_numpy(d).to(dev))
+    gen_s = time.perf_counter() - t0
+    nat.clear_caches()
+    steps = 2
+    dt, out, prof = timed_encodes(x, du, steps, 1, nat.MP_PATH_FFT, 0, None, n_iters=sh.K)
+    ls = nat.lazy_stats()
+    plain_dt, plain, _ = timed_encodes(x, du, 1, 0, nat.MP_PATH_FFT, 0, None, n_iters=sh.K, coherence=False)
+    nat.lazy_stats()
+    marked = int(torch.isnan(out[2]).any(dim=1).sum())
+    inc = nat.encode(x[:4], du, 16, path=nat.MP_PATH_INCREMENTAL)
+    torch.cuda.synchronize()
+    rec = torch.zeros_like(x)
+    nat.scatter(out[0], torch.arange(sh.B, device=dev)[:, None].expand(sh.B, sh.K), out[1], out[2], du, rec)
+    rt = float((rec + out[3] - x).abs().max())
+    rdb = 20 * torch.log10(out[3].norm(dim=-1) / x.norm(dim=-1))
+    nat.clear_caches()
+    res = {
+        "workload": sh.name, "value": round(sh.B * sh.K * steps / dt, 2), "unit": "segment-iterations/s",
+        "ms_per_step": round(dt / steps * 1e3, 3), "steps": steps, "warmup": 1,
+        "schedule": nat.last_schedule(), "segments_marked": marked,
+        "without_the_lazy_screen": {"value": round(sh.B * sh.K / plain_dt, 2), "ms_per_step": round(plain_dt * 1e3, 3),
+                                    "bit_identical": bool(all(torch.equal(p, q) for p, q in zip(out, plain)))},
+        "first_4_segments_x_16_steps_equal_incremental_mfma": bool(torch.equal(inc[0], out[0][:4, :16]) and
+                                                                   torch.equal(inc[1], out[1][:4, :16]) and
+                                                                   torch.equal(inc[2], out[2][:4, :16])),
+        "round_trip_max_err": rt, "residual_db_mean": round(float(rdb.mean()), 3),
+        "inputs_generated_s": round(gen_s, 1),
+        "roofline": roofline_fft(prof, sh, steps, lazy=ls),
+        "note": "coherence table (mp_coherence_f32, ~115 ms for 4096 x 2048) built once, in the warm-up encode; SURVEY.md 8(d)'s "
+                "HBM roofline for this config prices the reference's full-length transforms (2.18 GB per segment-iteration): "
+                "by it this run would move " + f"{2.181e9 * sh.B * sh.K * steps / dt / 1e12:.0f}" + " TB/s -- the screen does not do "
+                "that work (one 8192-point window of dirty lags per step, exact refinement); its own bound is VALU issue",
+    }
+    del x, rec, out, plain
+    torch.cuda.empty_cache()
+    return res
+
+
 def _free_port():
     with socket.socket() as sock:
         sock.bind(("127.0.0.1", 0))
@@ -401,6 +618,7 @@ def main():
                          "reported under variants.")
     ap.add_argument("--no-variants", action="store_true", help="skip the direct-path variant leg")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
+    ap.add_argument("--no-configs3", action="store_true", help="skip the BASELINE configs[3] full-size variant (~10 s)")
     ap.add_argument("--backend", default=None, help="torch.distributed backend (default nccl = RCCL)")
     ap.add_argument("--share-device", action="store_true",
                     help="rehearsal only: every rank uses cuda:0 (with --backend gloo on a one-GPU box)")
@@ -441,7 +659,7 @@ def main():
     atom, lag, gain, residual = [t.cpu().numpy() for t in out]
     seg_its = world * B_PER_GPU * K_ITERS * args.steps
     if path == nat.MP_PATH_FFT:
-        roof = (roofline_persistent if ran_persistent() else roofline_fft)(prof, B_PER_GPU, args.steps)
+        roof = (roofline_persistent if ran_persistent() else roofline_fft)(prof, HEAD, args.steps)
     else:
         roof = roofline_from(prof, algorithmic_flops(lag, path), args.steps)
     rdb = 20 * np.log10(np.linalg.norm(residual, axis=-1) / np.linalg.norm(x_host, axis=-1))
@@ -481,7 +699,7 @@ def main():
                 vlag = vout[1].cpu().numpy()
                 same = all(torch.equal(p, q) for p, q in zip(vout, out))
                 if other == nat.MP_PATH_FFT:
-                    vroof = (roofline_persistent if ran_persistent() else roofline_fft)(vprof, B_PER_GPU, vsteps)
+                    vroof = (roofline_persistent if ran_persistent() else roofline_fft)(vprof, HEAD, vsteps)
                 else:
                     vroof = roofline_from(vprof, algorithmic_flops(vlag, other), vsteps)
                 line["variants"][name] = {
@@ -489,6 +707,7 @@ def main():
                     "ms_per_step": round(vdt / vsteps * 1e3, 4), "steps": vsteps,
                     "bit_identical_to_headline": bool(same), "roofline": vroof,
                 }
+            line["variants"].update(non_ideal_variants(x, du, d, out, args.steps, group))
             # the library default once more, replayed from a captured hipGraph (mpcore.EncodePlan)
             nat.profile_enable(0)  # (no timing events inside the captured graph)
             plan = nat.EncodePlan(B_PER_GPU, N, du, K_ITERS, path=nat.MP_PATH_FFT)
@@ -505,11 +724,15 @@ def main():
                 "bit_identical_to_headline": bool(all(torch.equal(p, q) for p, q in zip(pout, out))),
                 "note": "includes the device copy of the batch into the plan's static input",
             }
+            if not args.no_configs3:
+                nat.profile_enable(PROF_EVERY)
+                line["variants"]["configs3_full_size"] = configs3_variant(dev)
         if not args.no_cpu:
             base, parity = cpu_baseline(d, x_host, (atom, lag, gain))
             line["cpu_baseline"] = base
             line["parity_vs_cpu_oracle"] = parity
             line["speedup_vs_cpu_baseline"] = round(line["value"] / base["value"], 1)
+            line["cpu_baseline_torch_ops"] = cpu_baseline_torch(d, x_host, (atom, lag, gain))
     nat.profile_enable(False)
     if rank == 0:
         print(json.dumps(line), flush=True)

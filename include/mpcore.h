@@ -247,10 +247,14 @@ int mp_last_schedule(void);
  * a transform (lazy screen).  Synchronises the device. */
 int mp_persist_stats(uint64_t *out16);
 
-/* Debug: the lazy screen of the launch-per-step form since the last read, summed over encodes -- out2[0] = (segment,
- * tile) screens skipped (their dirty cells kept widened bounds), out2[1] = (segment, tile) decisions made.  Synchronises
- * the device; resets the counters. */
-int mp_lazy_stats(uint64_t *out2);
+/* Debug: the lazy screen of the launch-per-step form since the last read, summed over encodes -- out8[0] = (segment,
+ * tile) screens skipped (their dirty cells kept widened bounds), out8[1] = (segment, tile) decisions made; selects that
+ * decided nothing because out8[2] a static condition failed (an atom cropped at the segment's end, a contender overflow),
+ * out8[3] more than two contender cells had been refined (near-ties), out8[4] the run's floor is 0, out8[5] there is no
+ * clean lower bound or the next window is all zeros.  Beside them, how much exact refinement the screens left to do:
+ * out8[6] = contender cells refined (whole cells, 32 chains each) by the launch-per-step fused select, out8[7] = contender
+ * quarter-cells (8 chains each) refined by the persistent form's selects.  Synchronises the device; resets the counters. */
+int mp_lazy_stats(uint64_t *out8);
 
 /* Debug (MP_TUNE_AUDIT): the largest |screen - exact| / eps over all cells audited since the last read, their
  * number, the same for quarter-cell maxima, and how many exceeded 1 (must be 0).  Synchronises the device;
@@ -293,6 +297,17 @@ int mp_scatter_rows_f32(const float *rows, const int64_t *batch, const int64_t *
  */
 int mp_gather_sum_f32(const float *x, int64_t B, int64_t N, const int64_t *batch,
                       const int64_t *lag, int64_t n_events, int64_t L, double *out, void *stream);
+
+/*
+ * The same for n_groups groups of events in one launch: group g owns events [offsets[g] - offsets[0],
+ * offsets[g + 1] - offsets[0]) of batch / lag (`offsets` may be a slice of a longer table: only differences count),
+ * out[g * L + i] = its window sum, fp64.  One dependency level of the multi-GPU dictionary_learning_step
+ * (modules/matchingpursuit.py:391-415 by levels: atoms of one level share no sample, so their add-backs, window sums
+ * and re-subtractions commute) -- what the ranks all-reduce is this ONE [n_groups, L] matrix per level instead of one
+ * [L] vector per atom.  n_groups <= 65535.
+ */
+int mp_gather_sum_groups_f32(const float *x, int64_t B, int64_t N, const int64_t *batch, const int64_t *lag,
+                             const int64_t *offsets, int64_t n_groups, int64_t L, double *out, void *stream);
 
 /*
  * Backward pass of mp_encode_conv_f32, i.e. of the analysis loop of the reference's gradient-trained model

@@ -897,6 +897,23 @@ __global__ void gather_sum_kernel(const float *__restrict__ x, int64_t N, const 
     out[s] = acc;
 }
 
+// ... the same for several groups of events at once (one dependency level of the multi-GPU dictionary update: what is
+// all-reduced is then ONE [groups, L] matrix per level): blockIdx.y = group, events off[g] .. off[g + 1] - 1 in order
+__global__ void gather_sum_groups_kernel(const float *__restrict__ x, int64_t N, const int64_t *__restrict__ batch,
+                                         const int64_t *__restrict__ lag, const int64_t *__restrict__ off, int64_t L,
+                                         double *__restrict__ out) {
+    const int64_t g = blockIdx.y;
+    const int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= L) return;
+    const int64_t e0 = off[g] - off[0], e1 = off[g + 1] - off[0];   // (offsets may be a slice of a longer table)
+    double acc = 0.0;
+    for (int64_t e = e0; e < e1; ++e) {
+        const int64_t t = lag[e] + s;
+        if (t >= 0 && t < N) acc += (double)x[batch[e] * N + t];
+    }
+    out[g * L + s] = acc;
+}
+
 // ------------------------------------------------------------------------------------------------
 // The atom-by-atom loop of dictionary_learning_step (modules/matchingpursuit.py:391-415) in ONE launch of ONE
 // workgroup: the loop is sequential by construction (every atom's update reads the residual the earlier
@@ -1635,18 +1652,17 @@ int fft_iteration(const Geom &g, const Workspace &w, const float *du, int K, int
                                    g.N, g.A, g.L, g.Ns, g.NBLK, g.NAT, K, k, rule.du_sub, rule.shift, rule.square,
                                    w.tw, w.xspec, w.wnorm, f.NW, (const float *)w.dscale, bsum,
                                    lazy_form && k >= 1 ? lz.mu : (const float *)nullptr, tau, lz.margin, lz.reuse,
-                                   (const float *)w.lfloor, lazy_form && k >= 1 ? w.skip : (unsigned *)nullptr);
+                                   (const float *)w.lfloor, lazy_form && k >= 1 ? w.skip : (unsigned *)nullptr, lz.force);
             })
             if (lazy_form && k == 0 && K > 2) {
-                // the lazy screen's floor: where this run's maxima are expected to end (mppersist.inc: rank K + K/16 + 1,
-                // peaks dominating `radius` blocks either side), from the summaries after step 0's select
-                const int radius = lazy_radius_for(g.L);
-                if (g.NBLK <= FLOOR_WAVE_MAXBLK)
-                    hipLaunchKernelGGL(persist_floor_wave_kernel, dim3((unsigned)g.B), dim3(64), 0, st, (const unsigned *)w.bsum,
-                                       g.NBLK, K + K / 16 + 1, radius, w.lfloor);
-                else
-                    hipLaunchKernelGGL(persist_floor_kernel, dim3((unsigned)g.B), dim3(256), 0, st, (const unsigned *)w.bsum,
-                                       g.NBLK, K + K / 16 + 1, radius, w.lfloor);
+                // the lazy screen's floor: where this run's maxima are expected to end -- the (K + K/16 + 1)-th largest peak
+                // among the CELLS after step 0's select (mplazy.inc: lazy_floor_cells_kernel; peaks dominate their own
+                // tile's cells `radius` blocks either side)
+                const int tuned = persist_radius.load(std::memory_order_relaxed);
+                const int radius = tuned > 0 ? tuned : tuned < 0 ? 0 : (int)(1 + std::max<int64_t>(0, (g.L - 512 + 255) / 256));
+                hipLaunchKernelGGL(lazy_floor_cells_kernel, dim3((unsigned)g.B), dim3(1024), 0, st, (const u64 *)w.keys,
+                                   (const float *)w.ceps, (const unsigned *)w.bsum, g.NBLK, g.NAT, lazy_rank_for(K), radius,
+                                   w.lfloor);
             }
         } else {
             // select-A merged into the refinement launch when select-B is the kernel that clears the slots
@@ -1906,6 +1922,8 @@ int mp_tune(int key, double value) {
     if (key == MP_TUNE_LAZY_REUSE && value >= 0 && value <= 4) { persist_reuse.store((int)value); return MP_OK; }
     if (key == MP_TUNE_LAZY_RADIUS && value >= -1 && value <= 64) { persist_radius.store((int)value); return MP_OK; }
     if (key == MP_TUNE_PERSIST_PRESCAN && (value == 0 || value == 1)) { persist_prescan.store((int)value); return MP_OK; }
+    if (key == 17 /* MP_TUNE_PERSIST_XPLAIN */ && (value == 0 || value == 1)) { persist_xplain.store((int)value); return MP_OK; }
+    if (key == 16 /* MP_TUNE_LAZY_FORCE: timing experiments only */ && value >= 0 && value < 3) { lazy_force.store((float)value); return MP_OK; }
     if (key == MP_TUNE_CLEAR_MEMSET && (value == 0 || value == 1)) { clear_with_memset.store((int)value); return MP_OK; }
     return fail(MP_ERR_ARG, "mp_tune: unknown key or bad value%s");
 }
@@ -2028,13 +2046,13 @@ static int encode_impl(const float *signal, int64_t B, int64_t N, const float *d
             float *lbfloor = reinterpret_cast<float *>(w.pctl + 256 + 512 * 64 + ((size_t)B * (K - 1) + 2) * 128);
             if (mu) {   // the lazy screen's floor: where this run's maxima are expected to end (mppersist.inc)
                 // (rank K + K/16 + 1: now and then one event leaves two peaks; radius 1 + ceil(max(0, L - 512) / 256) blocks)
-                const int radius = lazy_radius_for(L);
+                const int radius = lazy_radius_for(L, g.NBLK, K);
                 if (g.NBLK <= FLOOR_WAVE_MAXBLK)
                     hipLaunchKernelGGL(persist_floor_wave_kernel, dim3((unsigned)B), dim3(64), 0, st, (const unsigned *)w.bsum, g.NBLK,
-                                       K + K / 16 + 1, radius, lbfloor);
+                                       lazy_rank_for(K), radius, lbfloor);
                 else
                     hipLaunchKernelGGL(persist_floor_kernel, dim3((unsigned)B), dim3(256), 0, st, (const unsigned *)w.bsum, g.NBLK,
-                                       K + K / 16 + 1, radius, lbfloor);
+                                       lazy_rank_for(K), radius, lbfloor);
                 HIP_TRY(hipGetLastError());
             }
             rc = launch_persistent(g, f, w, dict_unit, rule, K, fft_tau(f.logM).tau, out_atom, out_lag, out_gain, st, mu, lbfloor);
@@ -2078,6 +2096,7 @@ static int encode_impl(const float *signal, int64_t B, int64_t N, const float *d
         lz.mu = coherence;
         lz.margin = persist_margin.load(std::memory_order_relaxed);
         lz.reuse = lazy_reuse_for(K);
+        lz.force = lazy_force.load(std::memory_order_relaxed);
     }
     // the K steps; whatever it returns, the forked streams are joined back into the caller's below
     auto run_steps = [&]() -> int {
@@ -2310,6 +2329,17 @@ int mp_gather_sum_f32(const float *x, int64_t B, int64_t N, const int64_t *batch
     return MP_OK;
 }
 
+int mp_gather_sum_groups_f32(const float *x, int64_t B, int64_t N, const int64_t *batch, const int64_t *lag,
+                             const int64_t *offsets, int64_t n_groups, int64_t L, double *out, void *stream) {
+    if (n_groups == 0) return MP_OK;
+    if (!x || !out || !offsets || L <= 0 || N <= 0 || B <= 0 || n_groups < 0 || n_groups > 65535)
+        return fail(MP_ERR_ARG, "mp_gather_sum_groups_f32: bad arguments%s");
+    hipLaunchKernelGGL(gather_sum_groups_kernel, dim3((unsigned)((L + 255) / 256), (unsigned)n_groups), dim3(256), 0,
+                       static_cast<hipStream_t>(stream), x, N, batch, lag, offsets, L, out);
+    HIP_TRY(hipGetLastError());
+    return MP_OK;
+}
+
 int mp_dictionary_update_f32(float *residual, float *sparse_zeroed, int64_t B, int64_t N, float *dict_work, int64_t A,
                              int64_t L, const int64_t *order, const int64_t *offsets, int64_t n_groups,
                              const int64_t *ev_batch, const int64_t *ev_lag, const float *ev_rows,
@@ -2417,9 +2447,9 @@ int mp_persist_stats(uint64_t *out8 /* [16] */) {
     return MP_OK;
 }
 
-int mp_lazy_stats(uint64_t *out2 /* [2] */) {
+int mp_lazy_stats(uint64_t *out2 /* [8] */) {
     if (!out2) return fail(MP_ERR_ARG, "mp_lazy_stats: null output%s");
-    const uint64_t zero[2] = {0, 0};
+    const uint64_t zero[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     HIP_TRY(hipDeviceSynchronize());
     HIP_TRY(hipMemcpyFromSymbol(out2, HIP_SYMBOL(g_lazy_stats), sizeof(zero)));
     HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(g_lazy_stats), zero, sizeof(zero)));

@@ -52,7 +52,7 @@ EXPORTS = (
     "mp_dictionary_update_f32", "mp_lcn_workspace_bytes", "mp_encode_lcn_f32", "mp_conv_model_backward_f32",
     "mp_stream_pair_ratio", "mp_init_streams", "mp_audit_read", "mp_dictionary_levels_host",
     "mp_dictionary_update_levels_f32", "mp_persist_stats", "mp_last_schedule", "mp_encode_lazy_f32",
-    "mp_coherence_f32", "mp_coherence_workspace_bytes", "mp_lazy_stats",
+    "mp_coherence_f32", "mp_coherence_workspace_bytes", "mp_lazy_stats", "mp_gather_sum_groups_f32",
 )
 
 
@@ -100,6 +100,7 @@ def lib():
         L.mp_scatter_f32.argtypes = [vp, vp, vp, vp, i64, vp, i64, i64, vp, i64, i64, vp]
         L.mp_scatter_rows_f32.argtypes = [vp, vp, vp, i64, i64, vp, i64, i64, vp]
         L.mp_gather_sum_f32.argtypes = [vp, i64, i64, vp, vp, i64, i64, vp, vp]
+        L.mp_gather_sum_groups_f32.argtypes = [vp, i64, i64, vp, vp, vp, i64, i64, vp, vp]
         L.mp_dictionary_update_f32.argtypes = [vp, vp, i64, i64, vp, i64, i64, vp, vp, i64, vp, vp, vp, vp,
                                                ctypes.c_float, vp, vp]
         L.mp_fft_c2c_f32.argtypes = [vp, vp, ctypes.c_int, i64, ctypes.c_int, vp, vp]
@@ -177,11 +178,14 @@ def persist_stats():
 
 
 def lazy_stats():
-    """mp_lazy_stats: dict(skipped, decided) -- (segment, tile) screens the launch-per-step lazy screen left out / decided on
-    since the last read (the persistent form counts its own in persist_stats()['skipped']).  Synchronises; resets."""
-    buf = (ctypes.c_uint64 * 2)()
+    """mp_lazy_stats: dict(skipped, decided, ...) -- (segment, tile) screens the launch-per-step lazy screen left out /
+    decided on since the last read, and the selects that decided nothing, by reason (the persistent form counts its own
+    in persist_stats()['skipped']).  Synchronises; resets."""
+    buf = (ctypes.c_uint64 * 8)()
     _check(lib().mp_lazy_stats(buf), "mp_lazy_stats")
-    return dict(skipped=int(buf[0]), decided=int(buf[1]))
+    return dict(skipped=int(buf[0]), decided=int(buf[1]), off_static=int(buf[2]), off_contenders=int(buf[3]),
+                off_no_floor=int(buf[4]), off_no_bound=int(buf[5]), contender_cells=int(buf[6]),
+                contender_quarters=int(buf[7]))
 
 
 def audit_read():
@@ -716,6 +720,24 @@ def gather_sum(x, batch, lag, L):
         rc = lib().mp_gather_sum_f32(_ptr(x), B, N, _ptr(batch), _ptr(lag), batch.numel(), L,
                                      _ptr(out), _stream(x))
     _check(rc, "mp_gather_sum_f32")
+    return out
+
+
+def gather_sum_groups(x, batch, lag, offsets, L):
+    """Per group g of events [offsets[g] - offsets[0], offsets[g + 1] - offsets[0]): sum over its events of
+    x[batch, lag:lag+L] (zero beyond N) -> float64 [G, L].  `offsets`: int64 device tensor [G + 1] (a slice is fine)."""
+    x = _f32(x)
+    _require_cuda(x)
+    dev = x.device
+    B, N = x.shape
+    batch, lag = _i64(batch, dev), _i64(lag, dev)
+    offsets = _i64(offsets, dev)
+    G = offsets.numel() - 1
+    out = torch.empty((max(G, 0), L), dtype=torch.float64, device=dev)
+    if G > 0:
+        with torch.cuda.device(dev):
+            rc = lib().mp_gather_sum_groups_f32(_ptr(x), B, N, _ptr(batch), _ptr(lag), _ptr(offsets), G, L, _ptr(out), _stream(x))
+        _check(rc, "mp_gather_sum_groups_f32")
     return out
 
 

@@ -11,8 +11,9 @@ from mpcore import synth
 A, L, N, B, K = 4096, 2048, 131072, 128, 256
 t0 = time.time()
 d = synth.make_dictionary(A, L, seed=4000)
-x = synth.make_segments(B, N, d, n_events=256, seed=4001)
-print(f"inputs generated in {time.time() - t0:.1f} s", flush=True)
+NE = int(os.environ.get("C4_EVENTS", 3 * K))   # E = 3 K planted events per segment
+x = synth.make_segments(B, N, d, n_events=NE, seed=4001)
+print(f"inputs generated in {time.time() - t0:.1f} s ({NE} planted events per segment)", flush=True)
 xd = torch.from_numpy(x).cuda()
 du = nat.unit_norm(torch.from_numpy(d).cuda())
 nat.encode(xd[:4], du, 2, path=nat.MP_PATH_FFT); torch.cuda.synchronize()
@@ -27,11 +28,24 @@ mu = nat.coherence_table(du)
 torch.cuda.synchronize()
 print(f"coherence table (second call): {(time.perf_counter() - t0) * 1e3:.1f} ms", flush=True)
 ref = None
-for name, flags, every, co in (("one stream, events around every launch", nat.MP_FLAG_NO_OVERLAP, 1, False),
+if os.environ.get("C4_PPS"):    # atom pairs per screen workgroup (16 = a whole tile)
+    nat.tune(nat.MP_TUNE_SCREEN_PPS, int(os.environ["C4_PPS"]))
+    print(f"screen pairs per workgroup {os.environ['C4_PPS']}", flush=True)
+if os.environ.get("C4_FORCE"):  # TIMING ONLY: random tile masks (1.p per tile, 2.p per segment); events are then wrong
+    nat.tune(16, float(os.environ["C4_FORCE"]))
+    print(f"forced random skip masks {os.environ['C4_FORCE']} (results invalid)", flush=True)
+if os.environ.get("C4_TUNE"):   # "margin,reuse": how the screen's time follows the share of tiles skipped
+    mg, ru = os.environ["C4_TUNE"].split(",")
+    nat.tune(nat.MP_TUNE_LAZY_MARGIN, float(mg)); nat.tune(nat.MP_TUNE_LAZY_REUSE, int(ru))
+    print(f"lazy margin {mg}, reuse {ru}", flush=True)
+RUNS = (("one stream", nat.MP_FLAG_NO_OVERLAP, 16, False), ("one stream, lazy screen", nat.MP_FLAG_NO_OVERLAP, 16, mu)) if os.environ.get("C4_SHORT") else None
+for name, flags, every, co in RUNS or (("one stream, events around every launch", nat.MP_FLAG_NO_OVERLAP, 1, False),
                                ("one stream", nat.MP_FLAG_NO_OVERLAP, 16, False),
                                ("one stream, lazy screen", nat.MP_FLAG_NO_OVERLAP, 16, mu),
                                ("one stream, lazy screen, events around every launch", nat.MP_FLAG_NO_OVERLAP, 1, mu),
+                               ("flags = 0, no table", 0, 0, False),
                                ("library default (table from the cache)", 0, 0, None),
+                               ("library default again", 0, 0, None),
                                ("library default again", 0, 0, None)):
     nat.profile_enable(every); nat.profile_read(); nat.lazy_stats()
     t0 = time.perf_counter()

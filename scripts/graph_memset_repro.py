@@ -99,6 +99,31 @@ def main():
                         where = torch.nonzero(w64 == vals[i]).flatten()
                         print(f"        8-byte value {v:#018x} x {int(counts[i])}, first at byte offset {int(where[0]) * 8}, "
                               f"last at {int(where[-1]) * 8}")
+            if memset and not inside:
+                # the same graph, replayed TWICE with nothing launched in between (no comparison, no copy, no print), then
+                # looked at once: does a replay go wrong by itself, or through what the process launches between replays?
+                g.replay()
+                g.replay()
+                torch.cuda.synchronize()
+                st = nat.persist_stats()
+                same = all(torch.equal(p, q) for p, q in zip(outs, ref))
+                print(f"    two replays back to back, then one look: identical {same}; launch error word {st['error']}, finished {st['finished']}")
+                g.replay()
+                torch.cuda.synchronize()
+                st = nat.persist_stats()
+                same = all(torch.equal(p, q) for p, q in zip(outs, ref))
+                print(f"    one more replay after that look: identical {same}; launch error word {st['error']}, finished {st['finished']}")
+                # a fresh capture of the same encode after all that: is its FIRST replay good again?
+                g2 = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g2, capture_error_mode="thread_local"):
+                    raw_encode(x, du, ws, outs)
+                for rep in range(2):
+                    g2.replay()
+                    torch.cuda.synchronize()
+                    st = nat.persist_stats()
+                    same = all(torch.equal(p, q) for p, q in zip(outs, ref))
+                    print(f"    fresh capture, replay {rep}: identical {same}; launch error word {st['error']}, finished {st['finished']}")
+                del g2
             del g
     nat.tune(nat.MP_TUNE_CLEAR_MEMSET, 0)
 

@@ -161,11 +161,61 @@ def test_hot_kernels_keep_their_register_budget():
     res = kr.kernel_resources()
     assert len(res) > 50
     screens = {n: r for n, r in res.items() if "17fft_screen_kernelILi" in n}
-    assert len(screens) == 8   # 2^10 .. 2^14, and the |.| variant of 2^10 .. 2^12 (the coherence table's screen)
+    assert len(screens) == 9   # 2^10 .. 2^14, and the |.| variant of 2^10 .. 2^13 (the coherence table's screen)
     for name, r in screens.items():
         assert r["spill"] == 0 and r["vgpr"] <= 128, (name, r)
     persistent = {n: r for n, r in res.items() if "correlate_persistent_kernel" in n}
     assert persistent and all(r["spill"] == 0 for r in persistent.values())
+
+
+def _kernel_resources_module():
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("kernel_resources", os.path.join(REPO, "scripts", "kernel_resources.py"))
+    kr = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(kr)
+    if not os.path.exists(kr.LIB) or not os.path.exists(os.path.join(kr.LLVM, "llvm-objdump")):
+        pytest.skip("needs the built library and the ROCm LLVM tools")
+    return kr
+
+
+def test_lds_reads_of_the_transform_are_consumed_behind_their_wait():
+    """csrc/mpfft.inc issues the transform's LDS reads as `asm volatile("ds_read_b64 ...")` and waits with a separate
+    `asm volatile("s_waitcnt lgkmcnt(0)")` -- an order the compiler cannot see: a multiply that consumed a read's
+    destination once moved in front of the wait (wrong picks in 31 of 60 encodes, no marker).  The
+    wait statement now carries the sixteen values as in/out operands; THIS is the check that it keeps working: in the
+    built code object, every ds_read_b64 of every kernel has its destination first read only after an s_waitcnt that
+    covers it (scripts/kernel_resources.py::lds_read_hazards walks the disassembly with the counter's semantics)."""
+    kr = _kernel_resources_module()
+    # the checker itself: a use before the wait is seen, a use behind it is not, lgkmcnt(n) covers the reads but the last n
+    bad = [(0, "ds_read_b64", "v[4:5], v1 offset:64"), (8, "v_pk_mul_f32", "v[6:7], v[4:5], v[8:9]"), (16, "s_waitcnt", "lgkmcnt(0)")]
+    good = [(0, "ds_read_b64", "v[4:5], v1 offset:64"), (8, "s_waitcnt", "lgkmcnt(0)"), (12, "v_pk_mul_f32", "v[6:7], v[4:5], v[8:9]")]
+    part = [(0, "ds_read_b64", "v[4:5], v1"), (8, "ds_read_b64", "v[6:7], v1 offset:8"), (16, "s_waitcnt", "lgkmcnt(1)"),
+            (20, "v_pk_add_f32", "v[10:11], v[4:5], v[4:5]"), (28, "v_pk_add_f32", "v[12:13], v[6:7], v[6:7]")]
+    store = [(0, "ds_read_b64", "v[4:5], v1"), (8, "ds_write_b64", "v2, v[4:5]")]
+    assert len(kr.lds_read_hazards(bad)) == 1 and kr.lds_read_hazards(good) == []
+    assert [h[0] for h in kr.lds_read_hazards(part)] == [28] and len(kr.lds_read_hazards(store)) == 1
+    reads = 0
+    for name in kr.kernel_resources():
+        insts = kr.kernel_instructions(name + ">:")
+        reads += sum(op == "ds_read_b64" for _, op, _ in insts)
+        assert kr.lds_read_hazards(insts) == [], name
+    assert reads > 1000   # (the transform is inlined into ~20 kernels, 56+ reads each)
+
+
+def test_bench_prices_the_screen_with_the_instruction_counts_of_the_built_code():
+    """bench.py's VALU roofline multiplies transforms by the VALU instructions one 16-point thread-transform costs; that
+    number is READ from the built code object (the pair loop of the kernel that ran: scripts/kernel_resources.py::
+    screen_pair_loop) and bench.py's table -- its fallback where the LLVM tools are missing -- must say the same."""
+    kr = _kernel_resources_module()
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench", os.path.join(REPO, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    for (kind, lg), want in bench.VALU_PER_THREAD_TRANSFORM.items():
+        got = kr.screen_pair_loop(kind, lg)
+        assert got["valu"] == want, (kind, lg, got)
+        assert got["barriers"] in (4, 6) and got["packed"] > 0.75 * got["valu"]
+    assert bench.valu_per_thread_transform("persistent", 11)[1] == "code object"
 
 
 def test_dictionary_levels_host_helper_matches_brute_force():

@@ -1,6 +1,6 @@
 """Two ranks sharing one MI355X (gloo for the collectives, the device for the work): the multi-GPU form of
-dictionary_learning_step -- per-atom window sums all-reduced in a globally consistent first-selection order --
-gives every rank the dictionary a single process computes from the concatenated batch."""
+dictionary_learning_step -- the atom-by-atom loop by global dependency levels, one [atoms in level, L] all-reduce of the
+window sums per level -- gives every rank the dictionary a single process computes from the concatenated batch."""
 import os
 import socket
 import sys
@@ -41,12 +41,13 @@ def _worker(rank, world, port, x_full, d, n_steps, ret):
     dist.destroy_process_group()
 
 
-def test_two_rank_dictionary_learning_step_equals_single_process():
+@pytest.mark.parametrize("A,L,N,B,K,ne", [(24, 64, 1500, 5, 6, 10),        # 5 segments: an uneven 3 + 2 split
+                                          (96, 128, 3000, 6, 24, 40)])     # crowded segments: many atoms share samples -> many levels
+def test_two_rank_dictionary_learning_step_equals_single_process(A, L, N, B, K, ne):
     from mpcore import synth
     import modules.matchingpursuit as mpm
-    A, L, N, B, K = 24, 64, 1500, 5, 6          # 5 segments: an uneven 3 + 2 split
     d = synth.make_dictionary(A, L, seed=61)
-    x = synth.make_segments(B, N, d, n_events=10, seed=62)
+    x = synth.make_segments(B, N, d, n_events=ne, seed=62)
     single = mpm.dictionary_learning_step(torch.from_numpy(x).to("cuda:0")[:, None, :], torch.from_numpy(d).to("cuda:0"),
                                           n_steps=K).cpu().numpy()
     ctx = mp.get_context("spawn")

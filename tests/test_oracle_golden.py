@@ -55,6 +55,30 @@ def test_oracle_encode_matches_reference(oracle, golden_dir, name):
     assert np.abs(rec - z["recon"]).max() <= REL * max(1.0, np.abs(z["recon"]).max())
 
 
+@pytest.mark.parametrize("name", ["encode_c1_16x256_n8192_b1_k8", "encode_mid_64x128_n4096_b3_k16",
+                                  "encode_ragged_24x100_n1000_b2_k12"])
+def test_torch_cpu_restatement_matches_reference_and_oracle(oracle, golden_dir, name):
+    """oracle/mp_oracle_torch.py -- the reference's loop in the torch CPU operators it calls itself (F.conv1d + torch.max,
+    modules/matchingpursuit.py:269-328), timed beside the C oracle as the second CPU baseline of SURVEY.md 8(d) -- picks
+    the reference's events and agrees with the C oracle to fp32 reordering noise."""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle"))
+    import mp_oracle_torch as mot
+    z = np.load(os.path.join(golden_dir, name + ".npz"))
+    du = mot.unit_norm(_raw_dict(z)).numpy()
+    assert np.abs(du - z["d_unit"]).max() <= 2e-7
+    K = z["atom"].shape[1]
+    out = mot.encode(z["signal"], du, K)
+    assert np.array_equal(out["atom"], z["atom"]) and np.array_equal(out["lag"], z["lag"])
+    assert np.abs(out["gain"] - z["gain"]).max() <= REL * np.abs(z["gain"]).max()
+    assert np.abs(out["residual"] - z["residual"]).max() <= REL * np.abs(z["signal"]).max()
+    want = oracle.encode(z["signal"], oracle.unit_norm(_raw_dict(z)), K)
+    assert np.array_equal(out["atom"], want["atom"]) and np.array_equal(out["lag"], want["lag"])
+    assert np.abs(out["gain"] - want["gain"]).max() <= REL * np.abs(want["gain"]).max()
+    rate, dt, _ = mot.timed_encode(z["signal"], du, 2, threads=2)
+    assert rate > 0 and dt > 0
+
+
 LCN_GOLDEN = ["encode_lcn_24x100_n1000_b2_k10", "encode_lcn_64x128_n4096_b3_k12", "encode_lcn_7x33_n300_b2_k6"]
 
 
