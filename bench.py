@@ -15,15 +15,24 @@ MP_PATH_FFT, FFT screen + exact refinement, events bit-identical to the direct p
 persistent form -- step 0 as separate kernels, steps 1 .. K-1 of the whole batch in ONE launch, csrc/mppersist.inc -- with
 its lazy screen: the coherence table it needs, 0.45 ms, is computed by the first encode of a batch this size (from 64
 segments one call pays for it: mpcore/_native.py::encode), i.e. in the first warm-up step; with --warmup 0 inside the
-timed region).  `variants` carries the launch-per-step forms of the same schedule (one stream: the form whose
-per-step screen kernel has its own roofline; four sub-batches on forked streams), the default's replay from a
-captured hipGraph (mpcore.EncodePlan) and the two direct-correlation (MFMA) schedules with their own rooflines.
-`roofline` is for the dominant kernel from HIP events recorded inside the timed region on the launch stream (the
-persistent launch: one span per encode; launch-per-step forms: sampled every 16th iteration, see launch_times).
-For the FFT schedule the bound is packed-fp32 VALU issue, NOT HBM: the screen's spectra are L2 / Infinity-Cache
-resident, and the measured fabric traffic (`traffic`, from the committed PMC passes) over the kernel time is
-reported beside it as `hbm_gbs_measured` / `frac_hbm`.  `cpu_baseline` is the CPU oracle timed on this host
-(rank 0, N = 1 only).
+timed region).  `roofline` is for the dominant kernel from HIP events recorded inside the timed region on the launch
+stream (the persistent launch: one span per encode; launch-per-step forms: sampled every 16th iteration, see
+launch_times).  For the FFT schedule the bound is packed-fp32 VALU issue, NOT HBM: the screen's spectra are L2 /
+Infinity-Cache resident, and the measured fabric traffic (`traffic`, from the committed PMC passes) over the kernel time is
+reported beside it as `hbm_gbs_measured` / `frac_hbm`; the instruction count it multiplies with is READ from the built code
+object (valu_per_thread_transform).  `variants` (rank 0, N = 1 only), each with its own figures:
+  * the launch-per-step forms of the same schedule (one stream: the form whose per-step screen kernel has its own
+    roofline; sub-batches on forked streams), the default replayed from a captured hipGraph (mpcore.EncodePlan), the two
+    direct-correlation (MFMA) schedules with their rooflines;
+  * what the headline does not time: fft_new_dictionary_every_call (the coherence table rebuilt inside every call),
+    product_default_checked (mpcore.encode_packed: unit_norm, the checked entry point with its host synchronisation),
+    sparse_code_surface (the reference's call surface: sparse_code(flatten=True) + scatter_segments), unplanted_signal
+    and half_planted_signal (signals that are NOT sparse in the dictionary: marks, retries, contenders per select);
+  * configs3_full_size: BASELINE configs[3] (4096 x 2048 dictionary, 128 x 131072-sample segments, K = 256) on the
+    library default, one warm-up and two timed encodes, with the roofline of fft_screen_kernel<13>.
+`cpu_baseline` is the CPU oracle (oracle/mp_oracle.c) timed on this host (rank 0, N = 1 only); `cpu_baseline_torch_ops`
+is SURVEY.md 8(d)'s second CPU baseline -- the reference's loop in the torch CPU operators it calls itself (F.conv1d +
+torch.max, oracle/mp_oracle_torch.py) at all of the host's cores and at 8 threads.
 
 `python bench.py --gpus N` with N > 1 and no WORLD_SIZE in the environment starts its own N ranks
 (`python -m torch.distributed.run --nproc-per-node N bench.py ...` as a child process, before anything touches the

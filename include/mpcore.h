@@ -110,22 +110,36 @@ int mp_profile_enable(int every);
                                      number of screen tasks the batch can have in flight)                          */
 #define MP_TUNE_PERSIST_SELECTS 8 /* persistent form: how many of them are select workers (0 = min(segments, 48))    */
 #define MP_TUNE_LAZY_REUSE 12     /* lazy screen: how often a cell's bound may be widened before the cell is screened again the next
-                                     time it is dirty: 1 .. 4 (4 = no cap); 0 (default) = 4 up to 96 steps, 1 beyond           */
+                                     time it is dirty: 1 .. 4 (4 = no cap); 0 (default) = by form: inside the persistent launch 4
+                                     up to 96 steps and 1 beyond, between launches (the launch-per-step form) 4               */
 #define MP_TUNE_LAZY_MARGIN 10    /* lazy screen (mp_encode_lazy_f32): a tile is skipped when its dirty cells' widened upper
-                                     bounds stay below margin x the best lower bound of the untouched blocks (0 < margin <= 1,
-                                     default 0.7; any value is exact, smaller = fewer skips and fewer stale contenders)      */
+                                     bounds stay below margin x the best lower bound of the untouched blocks (0 < margin <= 1;
+                                     0 = the defaults: 0.7 inside the persistent launch, 0.85 between launches; any value is
+                                     exact, smaller = fewer skips and fewer stale contenders)                                */
 #define MP_TUNE_LAZY_RADIUS 13    /* lazy screen: the run's floor is the (K + K/16 + 1)-th largest PEAK among the blocks' lower bounds after step
                                      0 -- a block counts if it is the best within this many blocks either side; 0 (default) =
                                      by atom length, 1 + ceil(max(0, L - 512) / 256); -1 = every block counts (tests: the floor comes out too high).  Smaller = more skips, and stale contenders
                                      (overflow marks) on signals whose maxima collapse within the run                          */
 #define MP_TUNE_PERSIST_PRESCAN 14 /* persistent form: a select worker that holds an entry whose screen is still running scans the
                                      blocks that screen does not touch -- and refines their contenders -- meanwhile (1, default; 0: off) */
+#define MP_TUNE_LAZY_FORCE 16      /* TIMING EXPERIMENTS ONLY -- the events are WRONG while it is set: the launch-per-step lazy
+                                     screen's tile masks are drawn at random (1.p: every (segment, tile) skipped with probability
+                                     p; 2.p: every segment skips all its tiles with probability p; 0, default: off).  How the
+                                     screen's time follows the share and the pattern of skipped workgroups: DESIGN.md 4d       */
 #define MP_TUNE_CLEAR_MEMSET 15    /* debug: 1 = the encode's clears are hipMemsetAsync calls instead of one kernel launch (what a
                                      stream capture makes of memset nodes: scripts/graph_memset_repro.py); 0 (default) */
 int mp_tune(int key, double value);
 int mp_profile_read(double *ms, int64_t *count);
 
-/* Device bytes mp_encode_f32 needs in `workspace` for this problem (0 on bad arguments). */
+/* Device bytes mp_encode_f32 needs in `workspace` for this problem (0 on bad arguments).
+ * What is in it: the padded residual [B][~N + L], the dictionary image, one 8-byte key and one 4-byte
+ * bound per cell ([B][N / 64][A / 32]: 12 B per 2048 map values); MP_PATH_FFT adds the pair spectra (A / 2 transforms of M
+ * points x 8 B: 4 MiB at 512 x 512, 134 MB at 4096 x 2048), the full pass's window spectra ([B][ceil(N / V)][M] x 8 B),
+ * 16 B of quarter maxima per cell for segments of up to 16384 cells -- and, where the shape takes the persistent form
+ * (1024- to 4096-point transforms, <= 16384 cells per segment, K >= 2), ONE WINDOW RECORD PER SEGMENT AND STEP:
+ * B (K - 2) (M + 16) x 8 B -- 62 MiB at the headline shape, 0.54 GB for 128 segments x 256 steps of 2048-point
+ * transforms, capped at 2 GiB (a batch whose records would pass the cap runs launch per step and gets none).  The figure
+ * depends on K for that reason.  All of it is scratch: nothing in it outlives the call. */
 size_t mp_workspace_bytes(int64_t B, int64_t N, int64_t A, int64_t L, int K, int path);
 
 /*

@@ -1918,12 +1918,11 @@ int mp_tune(int key, double value) {
     if (key == MP_TUNE_PERSIST_SHARDS && value >= 0) { persist_shards.store((int)value); return MP_OK; }
     if (key == MP_TUNE_PERSIST_WORKERS && value >= 0) { persist_workers.store((int)value); return MP_OK; }
     if (key == MP_TUNE_PERSIST_SELECTS && value >= 0) { persist_selects.store((int)value); return MP_OK; }
-    if (key == MP_TUNE_LAZY_MARGIN && value > 0.0 && value <= 1.0) { persist_margin.store((float)value); return MP_OK; }
+    if (key == MP_TUNE_LAZY_MARGIN && value >= 0.0 && value <= 1.0) { persist_margin.store((float)value); return MP_OK; }   // 0: the defaults (0.7 inside the persistent launch, 0.85 between launches)
     if (key == MP_TUNE_LAZY_REUSE && value >= 0 && value <= 4) { persist_reuse.store((int)value); return MP_OK; }
     if (key == MP_TUNE_LAZY_RADIUS && value >= -1 && value <= 64) { persist_radius.store((int)value); return MP_OK; }
     if (key == MP_TUNE_PERSIST_PRESCAN && (value == 0 || value == 1)) { persist_prescan.store((int)value); return MP_OK; }
-    if (key == 17 /* MP_TUNE_PERSIST_XPLAIN */ && (value == 0 || value == 1)) { persist_xplain.store((int)value); return MP_OK; }
-    if (key == 16 /* MP_TUNE_LAZY_FORCE: timing experiments only */ && value >= 0 && value < 3) { lazy_force.store((float)value); return MP_OK; }
+    if (key == MP_TUNE_LAZY_FORCE && value >= 0 && value < 3) { lazy_force.store((float)value); return MP_OK; }
     if (key == MP_TUNE_CLEAR_MEMSET && (value == 0 || value == 1)) { clear_with_memset.store((int)value); return MP_OK; }
     return fail(MP_ERR_ARG, "mp_tune: unknown key or bad value%s");
 }
@@ -2094,8 +2093,8 @@ static int encode_impl(const float *signal, int64_t B, int64_t N, const float *d
     LazyArgs lz;
     if (path == MP_PATH_FFT && coherence && !conv_model) {
         lz.mu = coherence;
-        lz.margin = persist_margin.load(std::memory_order_relaxed);
-        lz.reuse = lazy_reuse_for(K);
+        lz.margin = lazy_margin_for(true);
+        lz.reuse = lazy_reuse_for(K, true);
         lz.force = lazy_force.load(std::memory_order_relaxed);
     }
     // the K steps; whatever it returns, the forked streams are joined back into the caller's below

@@ -35,6 +35,7 @@ if len(sys.argv) > 1 and sys.argv[1] == "capture-first":
 import ctypes
 nat.lib().mp_stream_pair_ratio.restype = ctypes.c_float
 nat.lib().mp_stream_pair_ratio.argtypes = [ctypes.c_int, ctypes.c_int]
+print("streams kept by the pool (seen to run side by side):", nat.init_streams())
 print("spin ratio of internal stream pairs (1 = side by side, 2 = one after the other):",
       {f"s{a}{b}": round(float(nat.lib().mp_stream_pair_ratio(a, b)), 2) for a, b in ((0, 1), (0, 2), (0, 3), (1, 2), (1, 3), (2, 3))})
 if "ratios-only" in sys.argv:

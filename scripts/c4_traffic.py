@@ -11,9 +11,17 @@ A, L, N = 4096, 2048, 131072
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 128
 K = int(sys.argv[2]) if len(sys.argv) > 2 else 6
 d = synth.make_dictionary(A, L, seed=4000)
-x = synth.make_segments(B, N, d, n_events=64, seed=4001)
+x = synth.make_segments(B, N, d, n_events=int(os.environ.get("C4_EVENTS", 64)), seed=4001)
 xd = torch.from_numpy(x).cuda()
 du = nat.unit_norm(torch.from_numpy(d).cuda())
-out = nat.encode(xd, du, K, path=nat.MP_PATH_FFT, flags=nat.MP_FLAG_NO_OVERLAP)
+co = False
+if os.environ.get("C4_LAZY") or os.environ.get("C4_FORCE"):   # the lazy screen (tile masks); C4_FORCE: random masks, timing only
+    co = nat.coherence_table(du)
+    if os.environ.get("C4_FORCE"):
+        nat.tune(nat.MP_TUNE_LAZY_FORCE, float(os.environ["C4_FORCE"]))
+    if os.environ.get("C4_TUNE"):
+        mg, ru = os.environ["C4_TUNE"].split(",")
+        nat.tune(nat.MP_TUNE_LAZY_MARGIN, float(mg)); nat.tune(nat.MP_TUNE_LAZY_REUSE, int(ru))
+out = nat.encode(xd, du, K, path=nat.MP_PATH_FFT, flags=nat.MP_FLAG_NO_OVERLAP, coherence=co)
 torch.cuda.synchronize()
 print("done", int(torch.isnan(out[2]).any()), flush=True)

@@ -67,7 +67,7 @@ try:
         if case % 10 == 9:
             print(f"{case + 1} cases, {bad} mismatches, {skipped} of {skipped + run} tasks skipped so far", flush=True)
 finally:
-    nat.tune(nat.MP_TUNE_LAZY_MARGIN, 0.7)
+    nat.tune(nat.MP_TUNE_LAZY_MARGIN, 0)
     nat.tune(nat.MP_TUNE_LAZY_REUSE, 0)
 print(f"segments marked: {marks_lazy} with the lazy screen (reuse {reuse}), {marks_ref} without", flush=True)
 print("lazy fuzz:", "OK" if not bad else f"{bad} MISMATCHES", f"({skipped} of {skipped + run} screen tasks answered without a transform)", flush=True)

@@ -305,7 +305,7 @@ def test_encode_checked_retries_lazy_marks_without_the_lazy_screen():
             assert not torch.isnan(out[2]).any()
             assert all(torch.equal(p, q) for p, q in zip(out, ref)), rep
     finally:
-        nat.tune(nat.MP_TUNE_LAZY_MARGIN, 0.7)
+        nat.tune(nat.MP_TUNE_LAZY_MARGIN, 0)
         nat.tune(nat.MP_TUNE_LAZY_REUSE, 0)
         nat.tune(nat.MP_TUNE_LAZY_RADIUS, 0)
 

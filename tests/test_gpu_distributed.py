@@ -141,4 +141,8 @@ def test_internal_streams_run_side_by_side_even_when_created_after_a_graph_captu
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
     line = [l for l in out.stdout.splitlines() if l.startswith("spin ratio")][0]
     ratios = ast.literal_eval(line[line.index("{"):])
-    assert len(ratios) == 6 and all(0.5 < r < 1.5 for r in ratios.values()), ratios
+    kept = int([l for l in out.stdout.splitlines() if l.startswith("streams kept")][0].rsplit(":", 1)[1])
+    # the pool keeps the candidates its own spin test saw overlapping (streams 0 .. kept - 1; the rest of the table are
+    # candidates it rejected, never used): at least two, and every pair of the kept ones side by side when measured again
+    assert len(ratios) == 6 and kept >= 2, (kept, ratios)
+    assert all(0.5 < r < 1.5 for k, r in ratios.items() if int(k[1]) < kept and int(k[2]) < kept), (kept, ratios)

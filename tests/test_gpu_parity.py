@@ -894,7 +894,7 @@ def test_lazy_screen_is_bit_identical_to_the_oracle(oracle):
         keep = ~(torch.isnan(first[2]).any(dim=1) | torch.isnan(plain[2]).any(dim=1))   # (marked segments are re-encoded by the caller)
         assert keep.sum() >= 90 and all(torch.equal(p[keep], q[keep]) for p, q in zip(first, plain))
     finally:
-        nat.tune(nat.MP_TUNE_LAZY_MARGIN, 0.7)
+        nat.tune(nat.MP_TUNE_LAZY_MARGIN, 0)
 
 
 def test_lazy_screen_of_the_launch_per_step_form_is_bit_identical_to_the_oracle(oracle):
@@ -931,7 +931,7 @@ def test_lazy_screen_of_the_launch_per_step_form_is_bit_identical_to_the_oracle(
                 for name, t in zip(("atom", "lag", "gain", "residual"), (a, l, g, r)):
                     assert np.array_equal(t.cpu().numpy()[keep], want[name][keep]), (A, L, margin, name)
     finally:
-        nat.tune(nat.MP_TUNE_LAZY_MARGIN, 0.7)
+        nat.tune(nat.MP_TUNE_LAZY_MARGIN, 0)
 
 
 def test_persistent_form_with_scarce_and_odd_worker_counts(oracle):
