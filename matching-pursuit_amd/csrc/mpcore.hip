@@ -114,6 +114,8 @@ struct Geom {
     int Lpp;       // NCH * KC  (dictionary k extent incl. zero padding)
     int64_t Ns;    // residual row stride in floats (zero padded past N)
     int MAXC;      // most 64-lag blocks one subtraction can dirty
+    int circ;      // FFT screen: 0 = by atom length (make_fft_geom); else log2 of a CIRCULAR transform of exactly N = 2^circ
+                   // points, every lag valid (the coherence table's pass: mp_coherence_f32)
 };
 
 Geom make_geom(int64_t B, int64_t N, int64_t A, int64_t L, int TA, int64_t window = 0) {
@@ -132,6 +134,7 @@ Geom make_geom(int64_t B, int64_t N, int64_t A, int64_t L, int TA, int64_t windo
     int nb = (int)((2 * L - 2) / LAGS_PER_WAVE) + 2;
     if (nb > g.NBLK) nb = g.NBLK;
     g.MAXC = nb;
+    g.circ = 0;
     return g;
 }
 
@@ -1844,14 +1847,14 @@ size_t mp_workspace_bytes(int64_t B, int64_t N, int64_t A, int64_t L, int K, int
 }
 
 // ---- the dictionary's coherence table (lazy screen) ---------------------------------------------------------------------
-// Row a of the pseudo-batch is atom a between L - 1 zeros on either side: its correlation with atom b at lag n is
-// sum_j d_a[j] d_b[j + (L - 1 - n)], every shift of the pair for n = 0 .. 2L - 2.  One full-pass FFT screen of the A rows
-// with |.| maxima (A * A / 2 pair transforms per window), then per (row, tile) the maximum over the blocks of
-// approx + 2 eps (eps bounds |screen - chain|, and the chain's own rounding is within eps too).
+// Row a of the pseudo-batch is atom a followed by zeros, Mc samples in all (coherence_geom): its CIRCULAR correlation with
+// atom b holds every shift of the pair.  One FFT screen of the A rows with |.| maxima (A * A / 2 pair transforms), then
+// per (row, tile) the maximum over the blocks of approx + 2 eps (eps bounds |screen - chain|, and the chain's own
+// rounding is within eps too).
 __global__ void coherence_rows_kernel(const float *__restrict__ d, int64_t A, int64_t L, int64_t Nrow, float *__restrict__ rows) {
     const int64_t a = blockIdx.y;
     for (int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; j < Nrow; j += (int64_t)gridDim.x * blockDim.x)
-        rows[a * Nrow + j] = (j >= L - 1 && j < 2 * L - 1) ? d[a * L + (j - (L - 1))] : 0.0f;
+        rows[a * Nrow + j] = j < L ? d[a * L + j] : 0.0f;
 }
 __global__ void coherence_reduce_kernel(const u64 *__restrict__ keys, const float *__restrict__ ceps, int NBLK, int NAT,
                                         float *__restrict__ out) {
@@ -1866,16 +1869,27 @@ __global__ void coherence_reduce_kernel(const u64 *__restrict__ keys, const floa
         out[a * NAT + t] = m;
     }
 }
+// Every shift of a pair of atoms from ONE circular transform of Mc >= 2 L - 1 points: with atom a in samples 0 .. L-1 of an
+// otherwise zero row of Mc samples, sum_k row[(t + k) mod Mc] d_b[k] is the pair's correlation at shift +t for t < L and at
+// shift -(Mc - t) for t > Mc - L (nothing wraps onto anything: L + L - 1 <= Mc).  The encode's own transform for this atom
+// length is 2 - 4 times larger (3 L + 190: a whole dirty run of valid lags per LINEAR correlation): 8192 points for
+// 2048-sample atoms, where 4096 do here -- 113 -> ~50 ms for the 4096 x 2048 dictionary, 0.45 -> ~0.2 ms for 512 x 512.
 static bool coherence_geom(int64_t A, int64_t L, Geom *g, FftGeom *f) {
     if (A <= 0 || L <= 0) return false;
-    *g = make_geom_for(A, 3 * L - 2, A, L, MP_PATH_FFT, 0);
-    return make_fft_geom(*g, f) && !f->split && f->logM >= 10 && f->logM <= 13;
+    Geom enc = make_geom_for(1, 3 * L, A, L, MP_PATH_FFT, 0);
+    FftGeom fe;
+    if (!make_fft_geom(enc, &fe) || fe.split || fe.logM < 10 || fe.logM > 13) return false;   // (where the lazy screen exists)
+    int lg = 10;
+    while ((1ll << lg) < 2 * L - 1) ++lg;
+    *g = make_geom_for(A, 1ll << lg, A, L, MP_PATH_FFT, 0);
+    g->circ = lg;
+    return make_fft_geom(*g, f) && !f->split && f->logM == lg;
 }
 size_t mp_coherence_workspace_bytes(int64_t A, int64_t L) {
     Geom g;
     FftGeom f;
     if (!coherence_geom(A, L, &g, &f)) return 0;
-    return carve(g, MP_PATH_FFT, nullptr, 1).bytes + 256 + (size_t)A * (3 * L - 2) * sizeof(float);
+    return carve(g, MP_PATH_FFT, nullptr, 1).bytes + 256 + (size_t)A * g.N * sizeof(float);
 }
 int mp_coherence_f32(const float *dict_unit, int64_t A, int64_t L, float *out, void *workspace, size_t workspace_bytes,
                      void *stream) {
@@ -1888,7 +1902,7 @@ int mp_coherence_f32(const float *dict_unit, int64_t A, int64_t L, float *out, v
     if (workspace_bytes < mp_coherence_workspace_bytes(A, L)) return fail(MP_ERR_WORKSPACE, "workspace too small%s");
     hipStream_t st = static_cast<hipStream_t>(stream);
     Workspace w = carve(g, MP_PATH_FFT, static_cast<char *>(workspace), 1);
-    const int64_t Nrow = 3 * L - 2;
+    const int64_t Nrow = g.N;   // (= the circular transform's size)
     float *rows = reinterpret_cast<float *>(static_cast<char *>(workspace) + ((w.bytes + 255) / 256) * 256);
     hipLaunchKernelGGL(coherence_rows_kernel, dim3((unsigned)((Nrow + 255) / 256), (unsigned)A), dim3(256), 0, st, dict_unit, A, L,
                        Nrow, rows);

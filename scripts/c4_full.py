@@ -39,6 +39,10 @@ if os.environ.get("C4_TUNE"):   # "margin,reuse": how the screen's time follows 
     nat.tune(nat.MP_TUNE_LAZY_MARGIN, float(mg)); nat.tune(nat.MP_TUNE_LAZY_REUSE, int(ru))
     print(f"lazy margin {mg}, reuse {ru}", flush=True)
 RUNS = (("one stream", nat.MP_FLAG_NO_OVERLAP, 16, False), ("one stream, lazy screen", nat.MP_FLAG_NO_OVERLAP, 16, mu)) if os.environ.get("C4_SHORT") else None
+if os.environ.get("C4_SHORT") == "groups":
+    RUNS = (("one stream, lazy screen", nat.MP_FLAG_NO_OVERLAP, 0, mu), ("two sub-batches, lazy screen", nat.MP_FLAG_OVERLAP | nat.flag_groups(2), 0, mu),
+            ("four sub-batches, lazy screen", nat.MP_FLAG_OVERLAP | nat.flag_groups(4), 0, mu), ("one stream, lazy screen", nat.MP_FLAG_NO_OVERLAP, 0, mu),
+            ("two sub-batches, lazy screen", nat.MP_FLAG_OVERLAP | nat.flag_groups(2), 0, mu))
 for name, flags, every, co in RUNS or (("one stream, events around every launch", nat.MP_FLAG_NO_OVERLAP, 1, False),
                                ("one stream", nat.MP_FLAG_NO_OVERLAP, 16, False),
                                ("one stream, lazy screen", nat.MP_FLAG_NO_OVERLAP, 16, mu),

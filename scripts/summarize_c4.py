@@ -6,8 +6,9 @@ import numpy as np
 src = sys.argv[1] if len(sys.argv) > 1 else "gpurun_out/r01_c4"
 dst = sys.argv[2] if len(sys.argv) > 2 else "profiles/r01_c4_summary.json"
 new = lambda pat: sorted(glob.glob(pat), key=os.path.getmtime)[-1]
-out = {"what": "BASELINE configs[3] shape (4096 x 2048 dictionary, 128 x 131072-sample segments), MP_PATH_FFT, one stream, "
-               "K=6: scripts/c4_traffic.py under rocprofv3 (separate --pmc passes and a --kernel-trace --stats pass)"}
+out = {"what": sys.argv[3] if len(sys.argv) > 3 else
+       "BASELINE configs[3] shape (4096 x 2048 dictionary, 128 x 131072-sample segments), MP_PATH_FFT, one stream, "
+       "K=6: scripts/c4_traffic.py under rocprofv3 (separate --pmc passes and a --kernel-trace --stats pass)"}
 for tag, cn in (("fetch", "FETCH_SIZE"), ("write", "WRITE_SIZE")):
     v = collections.defaultdict(list)
     for r in csv.DictReader(open(new(f"{src}/{tag}/*/*_counter_collection.csv"))):
