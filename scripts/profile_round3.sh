@@ -3,15 +3,17 @@
 # scripts/summarize_profiles.py / summarize_c4.py):
 #   bench.py on the FFT schedule -- the persistent default and the launch-per-step form -- under rocprofv3 (kernel trace +
 #   separate PMC passes), and the config-4 shape with the lazy screen of the launch-per-step form (fft_screen_kernel<13>,
-#   fft_select_fused_kernel<13>): scripts/c4_traffic.py 128 segments x 24 steps, SURVEY 8(d)'s 768 planted events.
+#   fft_select_fused_kernel<13>): scripts/c4_traffic.py 128 segments x 256 steps, SURVEY 8(d)'s 768 planted events.
 set -uo pipefail
 cd "$(dirname "$0")/.."
 export TMPDIR=/tmp
+if [ "${1:-all}" != "c4" ]; then
 bash scripts/profile_round.sh r03_persist fft "--no-configs3"
 bash scripts/profile_round.sh r03_fft fft "--flags 4096 --no-configs3"
+fi
 OUT="$PWD/gpurun_out/r03_c4"; mkdir -p "$OUT"
 export C4_LAZY=1 C4_EVENTS=768
-C4="python3 scripts/c4_traffic.py 128 24"
+C4="python3 scripts/c4_traffic.py 128 256"   # (the whole job: the share of tiles skipped is ~90 % in the first steps and ~65 % later)
 timeout -k 10 300 rocprofv3 --kernel-trace --stats -d "$OUT/kt" --output-format csv -- $C4 > "$OUT/kt.log" 2>&1; echo "c4 kt rc=$?"
 timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE -d "$OUT/fetch" --output-format csv -- $C4 > "$OUT/fetch.log" 2>&1; echo "c4 fetch rc=$?"
 timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE -d "$OUT/write" --output-format csv -- $C4 > "$OUT/write.log" 2>&1; echo "c4 write rc=$?"
