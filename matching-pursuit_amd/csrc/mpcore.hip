@@ -2082,9 +2082,13 @@ static int encode_impl(const float *signal, int64_t B, int64_t N, const float *d
         }
     }
     int n_groups = 1;
+    // (segments of 65536 cells and more: their screens fill the GPU alone -- sub-batches measured level, 0.878 against
+    //  0.879 s at the config-4 shape -- until the lazy screen takes two thirds of the screen's workgroups out: then the
+    //  0.15 ms select between two 1.2 ms screens is a tenth of the step, and four sub-batches hide most of it: 0.425 ->
+    //  0.398 s, three runs each, scripts/c4_full.py)
     if (K > 0 && !(flags & MP_FLAG_NO_OVERLAP) &&
         (((flags & MP_FLAG_OVERLAP) && B >= 8) ||
-         (path == MP_PATH_FFT && B >= 48 && (int64_t)g.NBLK * g.NAT < 65536))) {  // big screens fill the GPU alone
+         (path == MP_PATH_FFT && B >= 48 && ((int64_t)g.NBLK * g.NAT < 65536 || (coherence && !conv_model))))) {
         const int per_call = (flags >> MP_FLAG_GROUPS_SHIFT) & 7;                  // MP_FLAG_GROUPS(n): this call only
         const int dflt = overlap_groups.load(std::memory_order_relaxed);
         n_groups = per_call >= 2 && per_call <= MAX_GROUPS ? per_call : (dflt >= 2 && dflt <= MAX_GROUPS ? dflt : 4);

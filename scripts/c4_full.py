@@ -42,7 +42,13 @@ RUNS = (("one stream", nat.MP_FLAG_NO_OVERLAP, 16, False), ("one stream, lazy sc
 if os.environ.get("C4_SHORT") == "groups":
     RUNS = (("one stream, lazy screen", nat.MP_FLAG_NO_OVERLAP, 0, mu), ("two sub-batches, lazy screen", nat.MP_FLAG_OVERLAP | nat.flag_groups(2), 0, mu),
             ("four sub-batches, lazy screen", nat.MP_FLAG_OVERLAP | nat.flag_groups(4), 0, mu), ("one stream, lazy screen", nat.MP_FLAG_NO_OVERLAP, 0, mu),
-            ("two sub-batches, lazy screen", nat.MP_FLAG_OVERLAP | nat.flag_groups(2), 0, mu))
+            ("two sub-batches, lazy screen", nat.MP_FLAG_OVERLAP | nat.flag_groups(2), 0, mu),
+            ("four sub-batches, lazy screen", nat.MP_FLAG_OVERLAP | nat.flag_groups(4), 0, mu),
+            ("three sub-batches, lazy screen", nat.MP_FLAG_OVERLAP | nat.flag_groups(3), 0, mu),
+            ("one stream, lazy screen", nat.MP_FLAG_NO_OVERLAP, 0, mu),
+            ("four sub-batches, lazy screen", nat.MP_FLAG_OVERLAP | nat.flag_groups(4), 0, mu),
+            ("four sub-batches, no table", nat.MP_FLAG_OVERLAP | nat.flag_groups(4), 0, False),
+            ("one stream, no table", nat.MP_FLAG_NO_OVERLAP, 0, False))
 for name, flags, every, co in RUNS or (("one stream, events around every launch", nat.MP_FLAG_NO_OVERLAP, 1, False),
                                ("one stream", nat.MP_FLAG_NO_OVERLAP, 16, False),
                                ("one stream, lazy screen", nat.MP_FLAG_NO_OVERLAP, 16, mu),

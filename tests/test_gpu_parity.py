@@ -787,7 +787,9 @@ def test_which_form_the_default_schedule_takes():
 def test_coherence_table_bounds_the_exact_one():
     """mp_coherence_f32 (one |.| screen of the atoms against the dictionary) against the exact cross-correlations
     (mp_feature_map_f32 of every atom in a zero row): never below them, and above by no more than the screen's bound."""
-    for A, L in ((64, 256), (100, 300), (40, 1000)):
+    # (the table comes from CIRCULAR transforms of the smallest power of two >= 2 L - 1 -- csrc/mpcore.hip::coherence_geom:
+    #  the shapes sit on both sides of its boundaries: 2 L - 1 = 1023 -> 1024 points, 1025 -> 2048, 4095 -> 4096)
+    for A, L in ((64, 256), (100, 300), (40, 1000), (33, 512), (48, 513), (40, 2048), (36, 2049)):
         du = nat.unit_norm(torch.from_numpy(synth.make_dictionary(A, L, seed=A + L)).to(DEV))
         exact = nat.coherence_table(du, exact=True)
         fast = nat.coherence_table(du)
