@@ -306,7 +306,7 @@ def roofline_persistent(prof, sh, steps):
     wave_instr = transforms * waves * valu
     avg_s = ms_p / n_p * 1e-3
     achieved = wave_instr / avg_s / 1e9
-    traffic = pmc_traffic("fft_persistent")
+    traffic = pmc_traffic("fft_persistent") if sh is HEAD else None   # (the PMC passes profiled the headline batch)
     t0 = sh.B * (sh.A // 2) * sh.nw_full
     out = {
         "bound": "valu", "achieved": round(achieved, 1), "peak": round(PEAK_VALU_GINSTR, 1),
@@ -516,6 +516,17 @@ def non_ideal_variants(x, du, d, head_out, steps, group):
             "residual_db_mean": round(float(rdb.mean()), 3),
             "note": "encode_checked (the product default): marked segments are re-encoded without the lazy screen, then on "
                     "the incremental schedule; `value` includes those retries"}
+    # (e) twice the batch: where the launch is bound by its screen tasks' throughput instead of one segment's chain of steps
+    #     (64 segments keep ~77 % of the screen workers busy), with the persistent launch's own roofline
+    sh2 = Shape(HEAD.A, HEAD.L, HEAD.N, 2 * HEAD.B, HEAD.K, "the headline dictionary, 128 segments")
+    x2 = torch.cat([x, torch.from_numpy(synth.make_segments(HEAD.B, HEAD.N, d, n_events=3 * HEAD.K, seed=1002,
+                                                            first_index=100000)).to(x.device)])
+    nat.profile_enable(PROF_EVERY)
+    dt2, out2, prof2 = timed_encodes(x2, du, steps, 1, nat.MP_PATH_FFT, 0, group)
+    v["fft_128_segments"] = {
+        "value": round(sh2.B * sh2.K * steps / dt2, 2), "unit": "segment-iterations/s", "ms_per_step": round(dt2 / steps * 1e3, 4),
+        "steps": steps, "first_64_segments_bit_identical_to_headline": bool(all(torch.equal(p[:HEAD.B], q) for p, q in zip(out2, head_out))),
+        "roofline": roofline_persistent(prof2, sh2, steps) if ran_persistent() else None}
     nat.profile_enable(PROF_EVERY)
     return v
 
@@ -523,7 +534,8 @@ def non_ideal_variants(x, du, d, head_out, steps, group):
 def configs3_variant(dev):
     """BASELINE configs[3] at full size on the library default (FFT screen launch per step, fused whole-cell select with
     block summaries, lazy screen by tile mask): one warm-up encode (which also builds the dictionary's coherence table),
-    two timed ones; roofline of fft_screen_kernel<13> from HIP events inside the timed region."""
+    two timed ones on the default (four sub-batches on forked streams); the roofline of fft_screen_kernel<13> from the HIP
+    events of one more encode on one stream, where its launches do not overlap."""
     sh = C3
     t0 = time.perf_counter()
     d = synth.make_dictionary(sh.A, sh.L, seed=4000)
@@ -534,8 +546,16 @@ def configs3_variant(dev):
     gen_s = time.perf_counter() - t0
     nat.clear_caches()
     steps = 2
-    dt, out, prof = timed_encodes(x, du, steps, 1, nat.MP_PATH_FFT, 0, None, n_iters=sh.K)
+    nat.profile_enable(0)
+    dt, out, _ = timed_encodes(x, du, steps, 1, nat.MP_PATH_FFT, 0, None, n_iters=sh.K)
+    schedule = nat.last_schedule()
+    # the screen kernel's own durations: the same encode once more on ONE stream (the default cuts this batch into four
+    # sub-batches whose launches overlap -- their spans would add up to several times the wall clock)
+    nat.profile_enable(PROF_EVERY)
+    one_dt, one, prof = timed_encodes(x, du, 1, 0, nat.MP_PATH_FFT, nat.MP_FLAG_NO_OVERLAP, None, n_iters=sh.K,
+                                      coherence=nat.cached_coherence(du))
     ls = nat.lazy_stats()
+    nat.profile_enable(0)
     plain_dt, plain, _ = timed_encodes(x, du, 1, 0, nat.MP_PATH_FFT, 0, None, n_iters=sh.K, coherence=False)
     nat.lazy_stats()
     marked = int(torch.isnan(out[2]).any(dim=1).sum())
@@ -549,7 +569,9 @@ def configs3_variant(dev):
     res = {
         "workload": sh.name, "value": round(sh.B * sh.K * steps / dt, 2), "unit": "segment-iterations/s",
         "ms_per_step": round(dt / steps * 1e3, 3), "steps": steps, "warmup": 1,
-        "schedule": nat.last_schedule(), "segments_marked": marked,
+        "schedule": schedule, "segments_marked": marked,
+        "one_stream": {"value": round(sh.B * sh.K / one_dt, 2), "ms_per_step": round(one_dt * 1e3, 3),
+                       "bit_identical": bool(all(torch.equal(p, q) for p, q in zip(out, one)))},
         "without_the_lazy_screen": {"value": round(sh.B * sh.K / plain_dt, 2), "ms_per_step": round(plain_dt * 1e3, 3),
                                     "bit_identical": bool(all(torch.equal(p, q) for p, q in zip(out, plain)))},
         "first_4_segments_x_16_steps_equal_incremental_mfma": bool(torch.equal(inc[0], out[0][:4, :16]) and
@@ -557,7 +579,7 @@ def configs3_variant(dev):
                                                                    torch.equal(inc[2], out[2][:4, :16])),
         "round_trip_max_err": rt, "residual_db_mean": round(float(rdb.mean()), 3),
         "inputs_generated_s": round(gen_s, 1),
-        "roofline": roofline_fft(prof, sh, steps, lazy=ls),
+        "roofline": roofline_fft(prof, sh, 1, lazy=ls),   # (of the one-stream encode above)
         "note": "coherence table (mp_coherence_f32, ~115 ms for 4096 x 2048) built once, in the warm-up encode; SURVEY.md 8(d)'s "
                 "HBM roofline for this config prices the reference's full-length transforms (2.18 GB per segment-iteration): "
                 "by it this run would move " + f"{2.181e9 * sh.B * sh.K * steps / dt / 1e12:.0f}" + " TB/s -- the screen does not do "
