@@ -1543,7 +1543,9 @@ int fft_iteration(const Geom &g, const Workspace &w, const float *du, int K, int
     const bool b_tail = !fused && !quarter && !(flags & MP_FLAG_FFT_SIMPLE) && f.logM >= 10 && f.logM <= 12;
     const bool fused_tail = (fused && f.logM >= 10) || b_tail || quarter;
     // (kept up to date by fft_screen_kernel only: not with the plain radix-4 screen)
-    unsigned *bsum = (fused && n_cells > QUARTER_MAX_CELLS && f.logM >= 10 && !(flags & MP_FLAG_FFT_SIMPLE)) ? w.bsum : nullptr;
+    // (... and whenever the fused select is to run the lazy screen, which decides on them: any size then -- that is how the
+    //  small shapes of the parity suite and the fuzz sweep reach it, with MP_FLAG_FFT_FUSED and a coherence table)
+    unsigned *bsum = (fused && (n_cells > QUARTER_MAX_CELLS || lz.mu) && f.logM >= 10 && !(flags & MP_FLAG_FFT_SIMPLE)) ? w.bsum : nullptr;
     if ((flags & MP_FLAG_FFT_PERSISTENT_BIT) && quarter) bsum = w.bsum;  // step 0 of the persistent schedule builds them too
     // The lazy screen on this form: the fused select decides, per segment, which tiles' dirty cells keep
     // their widened bounds -- a [B][4] mask the NEXT screen launch's workgroups leave on (config-4 shape: 8192-point

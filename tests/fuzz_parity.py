@@ -63,10 +63,14 @@ for case in range(n_cases):
     gap = (want["top2"][..., 0] - want["top2"][..., 1]) / np.maximum(np.abs(want["top2"][..., 0]), 1e-30)
     xd = torch.from_numpy(x).cuda(); dud = torch.from_numpy(du).cuda()
     mu = nat.coherence_table(dud) if nat.lib().mp_coherence_workspace_bytes(A, L) else None
-    for name, path, flags in paths + ([("fft_lazy", nat.MP_PATH_FFT, nat.MP_FLAG_FFT_PERSISTENT)] if mu is not None and K >= 2 else []):
-        a, l, g, r = nat.encode(xd, dud, K, path=path, flags=flags, coherence=mu if name == "fft_lazy" else False)
+    # (with the table: the lazy screen inside the persistent launch, and between launches -- the fused select's tile mask)
+    for name, path, flags in paths + ([("fft_lazy", nat.MP_PATH_FFT, nat.MP_FLAG_FFT_PERSISTENT),
+                                       ("fft_fused_lazy", nat.MP_PATH_FFT, nat.MP_FLAG_FFT_FUSED)] if mu is not None and K >= 2 else []):
+        a, l, g, r = nat.encode(xd, dud, K, path=path, flags=flags, coherence=mu if name.endswith("lazy") else False)
         if name == "fft_lazy":
             lazy_skipped += nat.persist_stats()["skipped"]
+        if name == "fft_fused_lazy":
+            lazy_skipped += nat.lazy_stats()["skipped"]
         a, l, g, r = a.cpu().numpy(), l.cpu().numpy(), g.cpu().numpy(), r.cpu().numpy()
         nanrow = np.isnan(g).any(axis=1)
         marked += int(nanrow.sum())

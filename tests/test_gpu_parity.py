@@ -906,7 +906,12 @@ def test_lazy_screen_of_the_launch_per_step_form_is_bit_identical_to_the_oracle(
     once (csrc/mpfft.inc: fft_select_fused_kernel / fft_screen_kernel).  Same events as the oracle, bit for bit, at any
     margin; tiles really are skipped; without the table nothing is."""
     try:
-        for A, L, N, B, K, flags in ((512, 128, 70400, 6, 24, 0), (160, 2048, 300000, 2, 6, nat.MP_FLAG_FFT_FUSED)):
+        # (two shapes that take the form by their size, and small ones that reach it with MP_FLAG_FFT_FUSED: an odd atom
+        #  count, tiles that are not full, a segment barely longer than its atoms, more steps than planted events)
+        for A, L, N, B, K, flags in ((512, 128, 70400, 6, 24, 0), (160, 2048, 300000, 2, 6, nat.MP_FLAG_FFT_FUSED),
+                                     (70, 300, 5000, 3, 20, nat.MP_FLAG_FFT_FUSED), (33, 700, 9000, 2, 16, nat.MP_FLAG_FFT_FUSED),
+                                     (16, 256, 8192, 1, 8, nat.MP_FLAG_FFT_FUSED), (97, 128, 700, 4, 12, nat.MP_FLAG_FFT_FUSED),
+                                     (40, 1100, 3000, 2, 6, nat.MP_FLAG_FFT_FUSED)):
             d = synth.make_dictionary(A, L, seed=31 + A)
             du_np = oracle.unit_norm(d)
             du = torch.from_numpy(du_np).to(DEV)
@@ -927,7 +932,7 @@ def test_lazy_screen_of_the_launch_per_step_form_is_bit_identical_to_the_oracle(
                 torch.cuda.synchronize()
                 st = nat.lazy_stats()
                 assert nat.last_schedule() == 1 and st["decided"] == B * (K - 2) * ((A + 31) // 32), (A, L, margin, st)
-                assert margin < 0.7 or st["skipped"] > st["decided"] // 20, (A, L, margin, st)   # (0.3 may skip nothing)
+                assert margin < 0.7 or A * N < 10 ** 7 or st["skipped"] > st["decided"] // 20, (A, L, margin, st)   # (0.3 may skip nothing; the small shapes too)
                 keep = ~torch.isnan(g).any(dim=1).cpu().numpy()   # (a marked segment is re-encoded by the caller)
                 assert keep.sum() >= B - 1, (A, L, margin)
                 for name, t in zip(("atom", "lag", "gain", "residual"), (a, l, g, r)):
