@@ -2045,9 +2045,32 @@ static int encode_impl(const float *signal, int64_t B, int64_t N, const float *d
     //  segment included: 512 x 512, persistent / one stream 48 / 41 k at 1 segment, 94 / 75 at 2, 181 / 137 at 4, 250 / 187
     //  at 6; 256 x 1024: 42 / 33, 78 / 62, 145 / 113, 207 / 159; 64 x 300: 54 / 48, 105 / 92, 204 / 186, 302 / 272, 600 /
     //  516 at 12.)
-    const bool persist_size = true;
+    // ... but not at every LOAD (round 3, scripts/form_sweep.py: six dictionaries x 8 .. 256 segments, with and without the
+    // table).  The one-launch form wins while a step is a chain of latencies; once the screens of a step are enough work to
+    // fill the chip for long, what counts is the rate at which transforms get done, and there the plain screen kernel (four
+    // wavefronts per SIMD, sixteen pairs per workgroup, workgroups of one tile side by side: its pair spectra shared in
+    // the L2s) does more than the queue's tasks (three per SIMD, four pairs per slot, tiles interleaved) -- above all where
+    // the pair spectra outgrow the L2s (1024 x 1024: 16.8 MB, persistent 190 k segment-iterations/s at ANY batch from 32
+    // segments up against 256 - 274 k launch per step).  With the table the launch-per-step side is the fused select with
+    // its lazy screen on sub-batches.  Transform points per step = B x ceil(A / 2) x M:
+    //   with the table    512 x 512:  67 M (128 segments) persistent 1224 against 1119 k, 134 M (256) 1217 against 1348
+    //                    1024 x 512:  67 M (64) 652 / 567,  134 M (128) 681 / 703       256 x 1024: 134 M (256) 1336 / 1299
+    //                    1024 x 1024: 67 M (32) 305 / 251,  134 M (64) 318 / 376, 268 M (128) 319 / 498
+    //                     512 x 256 (1024-point transforms): 17 M (64) 1296 / 981,  34 M (128) 1310 / 1431, 67 M 1252 / 1620
+    //   without           level up to 134 M while the pair spectra fit (<= 8 MB); 1024 x 1024: 34 M (16) 177 / 178, 67 M 187 / 226
+    FftGeom fp;
+    bool persist_size = make_fft_geom(g, &fp);
+    if (persist_size) {
+        const double pairs = (double)((A + 1) / 2);
+        const double points = (double)B * pairs * fp.M;
+        persist_size = (coherence && !conv_model) ? points <= (fp.logM == 10 ? 24e6 : 96e6)
+                                                  : (pairs * fp.M * 8.0 <= 8.5e6 || points <= 40e6);
+    }
     const bool persist = path == MP_PATH_FFT && ((flags & MP_FLAG_FFT_PERSISTENT_BIT) || (persist_size && !(flags & forms))) &&
                          !audit_on.load(std::memory_order_relaxed);  // (the audit checks screens launch by launch)
+    // a shape the persistent form would take but for its load, with the table: the fused select, which has the lazy screen
+    if (path == MP_PATH_FFT && !persist && coherence && !conv_model && !(flags & forms) && fp.logM >= 10 && fp.logM <= 12 && !fp.split)
+        flags |= MP_FLAG_FFT_FUSED;
     if (persist) {
         FftGeom f;
         if (make_fft_geom(g, &f) && persist_eligible(g, f, w, K)) {
