@@ -70,7 +70,7 @@ extern "C" {
 #define MP_FLAG_FFT_PERSISTENT 65536 /* MP_PATH_FFT: steps 1 .. K-1 of the whole batch in ONE launch of resident workgroups that
                                         pull screen tasks from a queue while select workers serve the segments whose screens
                                         are complete (csrc/mppersist.inc).  Default at every batch size where it applies
-                                        (no split transforms, <= 16384 cells per segment, 1024 <= M <= 4096, <= 2 GiB of window records); this flag
+                                        (no split transforms, <= 65536 cells per segment and <= 4096 atoms, 1024 <= M <= 4096, <= 2 GiB of window records); this flag
                                         asks for it at any batch size; shapes it does not cover use the other forms   */
 #define MP_FLAG_FFT_NO_PERSISTENT 131072 /* MP_PATH_FFT: launch-per-step kernels (sub-batches on forked streams from 48 segments) */
 #define MP_FLAG_GROUPS_SHIFT 20
@@ -135,8 +135,8 @@ int mp_profile_read(double *ms, int64_t *count);
  * What is in it: the padded residual [B][~N + L], the dictionary image, one 8-byte key and one 4-byte
  * bound per cell ([B][N / 64][A / 32]: 12 B per 2048 map values); MP_PATH_FFT adds the pair spectra (A / 2 transforms of M
  * points x 8 B: 4 MiB at 512 x 512, 134 MB at 4096 x 2048), the full pass's window spectra ([B][ceil(N / V)][M] x 8 B),
- * 16 B of quarter maxima per cell for segments of up to 16384 cells -- and, where the shape takes the persistent form
- * (1024- to 4096-point transforms, <= 16384 cells per segment, K >= 2), ONE WINDOW RECORD PER SEGMENT AND STEP:
+ * 16 B of quarter maxima per cell for segments of up to 16384 cells (65536 where the persistent form applies) -- and, where the shape takes the persistent form
+ * (1024- to 4096-point transforms, <= 65536 cells per segment, K >= 2), ONE WINDOW RECORD PER SEGMENT AND STEP:
  * B (K - 2) (M + 16) x 8 B -- 62 MiB at the headline shape, 0.54 GB for 128 segments x 256 steps of 2048-point
  * transforms, capped at 2 GiB (a batch whose records would pass the cap runs launch per step and gets none).  The figure
  * depends on K for that reason.  All of it is scratch: nothing in it outlives the call. */

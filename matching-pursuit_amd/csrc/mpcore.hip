@@ -98,6 +98,7 @@ constexpr int MP_FLAG_INTERNAL_ONE_STREAM = 1 << 30;  // set by encode_impl: the
 constexpr int MP_FLAG_INTERNAL_COHERENCE = 1 << 29;   // set by mp_coherence_f32: |.| screen only
 constexpr int64_t QUARTER_MAX_CELLS = 16384;  // FFT path: segments this small use the quarter-cell select kernel
 constexpr int64_t FUSED_MIN_CELLS = 65536;    // FFT path: from here the whole-cell one-kernel select, with block summaries
+constexpr int64_t PERSIST_MAX_CELLS = 65536;  // FFT path: the persistent form's quarter maxima are kept up to here (16 B per cell)
 
 __host__ __device__ inline int64_t round_up(int64_t x, int64_t m) { return (x + m - 1) / m * m; }
 
@@ -1171,7 +1172,10 @@ Workspace carve(const Geom &g, int path, char *base, int K = 0) {
             size_t o_ek = take((size_t)g.B * (MAXCONT + 1) * sizeof(u64));
             size_t o_ds = take(256);
             size_t o_bs = take((size_t)g.B * g.NBLK * 2 * sizeof(unsigned));
-            const bool quarters = (int64_t)g.NBLK * g.NAT <= QUARTER_MAX_CELLS;
+            // quarter maxima: for the quarter-cell select kernel (<= QUARTER_MAX_CELLS) and for the persistent form, whose select
+            // reads them cell by cell (1024- to 4096-point transforms, <= PERSIST_MAX_CELLS: larger dictionaries / longer segments)
+            const bool quarters = (int64_t)g.NBLK * g.NAT <= QUARTER_MAX_CELLS ||
+                                  ((int64_t)g.NBLK * g.NAT <= PERSIST_MAX_CELLS && !f.split && f.logM >= 10 && f.logM <= 12 && g.NAT <= 128);
             size_t o_sk = take(quarters ? (size_t)g.B * g.NBLK * g.NAT * SUBCELLS * sizeof(float) : 0);
             size_t o_lz = take((size_t)g.B * 4 * sizeof(unsigned));
             size_t o_lf = take((size_t)g.B * sizeof(float));
@@ -1525,9 +1529,13 @@ int fft_iteration(const Geom &g, const Workspace &w, const float *du, int K, int
     // scanning them dominates (measured: config-4 shape 190 vs 315 us per step; headline shape 35 vs 26 us).
     // MP_FLAG_FFT_FUSED / MP_FLAG_FFT_UNFUSED force either form.  A team of workgroups per segment inside
     // one kernel was tried and dropped: agent-scope fences between its members cost 3-13 us each.
-    const bool fused = !(flags & MP_FLAG_REFINE_MFMA) && !(flags & MP_FLAG_FFT_UNFUSED) &&
+    // (step 0 of the persistent form for segments of more than QUARTER_MAX_CELLS cells: the quarter-cell select kernel keeps
+    //  a whole segment's keys in registers and stops there -- the fused select takes its place, behind a screen that
+    //  still leaves the quarter maxima and block summaries the launch's selects read)
+    const bool pstep0_big = (flags & MP_FLAG_FFT_PERSISTENT_BIT) && w.subk && n_cells > QUARTER_MAX_CELLS && f.logM >= 10;
+    const bool fused = pstep0_big || (!(flags & MP_FLAG_REFINE_MFMA) && !(flags & MP_FLAG_FFT_UNFUSED) &&
                        ((flags & MP_FLAG_FFT_FUSED) || n_cells >= FUSED_MIN_CELLS ||
-                        (n_cells > QUARTER_MAX_CELLS && g.L <= 512));  // mid sizes: only while a cell's chains are short
+                        (n_cells > QUARTER_MAX_CELLS && g.L <= 512)));  // mid sizes: only while a cell's chains are short
     // both forms leave the next step's window spectrum behind when the screen's register transform exists
     // for this size (the stand-alone window kernel then runs before the first step only)
     // ... or, for small segments, ONE kernel that refines only a quarter of a contender cell (needs the screen's
@@ -1536,7 +1544,7 @@ int fft_iteration(const Geom &g, const Workspace &w, const float *du, int K, int
     // 1-2 % ahead, with two sub-batches on forked streams the quarter kernel is 3 % ahead -- so each gets the
     // schedule it is better under (MP_FLAG_FFT_QUARTER / MP_FLAG_FFT_NO_QUARTER force either).
     const bool two_launch_ok = f.logM <= 12 && n_cells <= 16384;
-    const bool quarter = w.subk && f.logM >= 10 &&
+    const bool quarter = w.subk && f.logM >= 10 && n_cells <= QUARTER_MAX_CELLS &&
                          !(flags & (MP_FLAG_REFINE_MFMA | MP_FLAG_FFT_UNFUSED | MP_FLAG_FFT_FUSED | MP_FLAG_FFT_SIMPLE |
                                     MP_FLAG_FFT_NO_QUARTER)) &&
                          ((flags & MP_FLAG_FFT_QUARTER) || !((flags & MP_FLAG_INTERNAL_ONE_STREAM) && two_launch_ok));
@@ -1546,7 +1554,7 @@ int fft_iteration(const Geom &g, const Workspace &w, const float *du, int K, int
     // (... and whenever the fused select is to run the lazy screen, which decides on them: any size then -- that is how the
     //  small shapes of the parity suite and the fuzz sweep reach it, with MP_FLAG_FFT_FUSED and a coherence table)
     unsigned *bsum = (fused && (n_cells > QUARTER_MAX_CELLS || lz.mu) && f.logM >= 10 && !(flags & MP_FLAG_FFT_SIMPLE)) ? w.bsum : nullptr;
-    if ((flags & MP_FLAG_FFT_PERSISTENT_BIT) && quarter) bsum = w.bsum;  // step 0 of the persistent schedule builds them too
+    if ((flags & MP_FLAG_FFT_PERSISTENT_BIT) && (quarter || pstep0_big)) bsum = w.bsum;  // step 0 of the persistent schedule builds them too
     // The lazy screen on this form: the fused select decides, per segment, which tiles' dirty cells keep
     // their widened bounds -- a [B][4] mask the NEXT screen launch's workgroups leave on (config-4 shape: 8192-point
     // transforms, where the launch-per-step form is work-bound on its screens).  From step 1's select on: the floor it
@@ -1598,8 +1606,8 @@ int fft_iteration(const Geom &g, const Workspace &w, const float *du, int K, int
                 const int64_t tasks = (int64_t)nw * g.NAT * g.B;
                 while (pps > 1 && tasks * (16 / (C::SLOTS * pps)) < 8 * (int64_t)num_cus()) pps >>= 1;
                 if (const int po = screen_pps_override.load(std::memory_order_relaxed); po > 0 && 16 % (C::SLOTS * po) == 0) pps = po;
-                if (quarter) pps = 4;  // one slot = one quarter of a tile
-                float *subk = quarter ? w.subk : nullptr;
+                if (quarter || pstep0_big) pps = 4;  // one slot = one quarter of a tile
+                float *subk = (quarter || pstep0_big) ? w.subk : nullptr;
                 const size_t lds_s = ((size_t)C::SLOTS * C::M + C::M / 64 + 64) * sizeof(cpx);
                 // pair spectra that cannot stay in the L2s: segment-fastest grid order (see the kernel)
                 const bool seg_fast = (size_t)g.NAT * f.NPT * f.M * sizeof(cpx) > (size_t)16 << 20;
@@ -2056,15 +2064,20 @@ static int encode_impl(const float *signal, int64_t B, int64_t N, const float *d
     //   with the table    512 x 512:  67 M (128 segments) persistent 1224 against 1119 k, 134 M (256) 1217 against 1348
     //                    1024 x 512:  67 M (64) 652 / 567,  134 M (128) 681 / 703       256 x 1024: 134 M (256) 1336 / 1299
     //                    1024 x 1024: 67 M (32) 305 / 251,  134 M (64) 318 / 376, 268 M (128) 319 / 498
-    //                     512 x 256 (1024-point transforms): 17 M (64) 1296 / 981,  34 M (128) 1310 / 1431, 67 M 1252 / 1620
-    //   without           level up to 134 M while the pair spectra fit (<= 8 MB); 1024 x 1024: 34 M (16) 177 / 178, 67 M 187 / 226
+    //                    2048 x 512:  67 M (32) 286 / 218,  134 M (64) 283 / 337
+    //                    1024-point transforms: 512 x 256: 17 M (64) 1296 / 981, 34 M (128) 1310 / 1431; 2048 x 256: 34 M (32)
+    //                    411 / 326, 67 M (64) 456 / 434, 134 M (128) 448 / 481; 4096 x 256: 34 M (16) 177 / 157, 134 M (64) 200 / 238
+    //                    (below 48 segments the launch-per-step side has one stream and a handful of select workgroups:
+    //                    the one-launch form wins there at every load measured)
+    //   without           level up to 134 M while the pair spectra fit (<= 8 MB; 2048 x 256 at 268 M: 356 / 397);
+    //                    1024 x 1024: 34 M (16) 177 / 178, 67 M 187 / 226; 2048 x 512: 34 M 175 / 164, 67 M 180 / 208
     FftGeom fp;
     bool persist_size = make_fft_geom(g, &fp);
     if (persist_size) {
         const double pairs = (double)((A + 1) / 2);
         const double points = (double)B * pairs * fp.M;
-        persist_size = (coherence && !conv_model) ? points <= (fp.logM == 10 ? 24e6 : 96e6)
-                                                  : (pairs * fp.M * 8.0 <= 8.5e6 || points <= 40e6);
+        persist_size = (coherence && !conv_model) ? (B < 48 || points <= (fp.logM == 10 ? 40e6 : 96e6))
+                                                  : ((pairs * fp.M * 8.0 <= 8.5e6 && points <= 200e6) || points <= 40e6);
     }
     const bool persist = path == MP_PATH_FFT && ((flags & MP_FLAG_FFT_PERSISTENT_BIT) || (persist_size && !(flags & forms))) &&
                          !audit_on.load(std::memory_order_relaxed);  // (the audit checks screens launch by launch)

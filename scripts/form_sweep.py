@@ -7,7 +7,7 @@ import numpy as np, torch
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "matching-pursuit_amd"))
 from mpcore import _native as nat, synth
 K = 32
-N = 32768
+N = int(os.environ.get('SWEEP_N', 32768))
 dicts = [(512, 512), (1024, 512), (256, 1024), (1024, 1024), (512, 256), (2048, 256)]
 if len(sys.argv) > 1:
     dicts = [tuple(int(v) for v in a.split("x")) for a in sys.argv[1:]]
