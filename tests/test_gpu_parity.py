@@ -920,9 +920,10 @@ def test_lazy_screen_of_the_launch_per_step_form_is_bit_identical_to_the_oracle(
     once (csrc/mpfft.inc: fft_select_fused_kernel / fft_screen_kernel).  Same events as the oracle, bit for bit, at any
     margin; tiles really are skipped; without the table nothing is."""
     try:
-        # (two shapes that take the form by their size, and small ones that reach it with MP_FLAG_FFT_FUSED: an odd atom
+        # (17 600 cells per segment with short atoms: the fused select by its size once the one-launch form is declined; 8192-point
+        #  transforms; and small shapes that reach the form with MP_FLAG_FFT_FUSED: an odd atom
         #  count, tiles that are not full, a segment barely longer than its atoms, more steps than planted events)
-        for A, L, N, B, K, flags in ((512, 128, 70400, 6, 24, 0), (160, 2048, 300000, 2, 6, nat.MP_FLAG_FFT_FUSED),
+        for A, L, N, B, K, flags in ((512, 128, 70400, 6, 24, nat.MP_FLAG_FFT_NO_PERSISTENT), (160, 2048, 300000, 2, 6, nat.MP_FLAG_FFT_FUSED),
                                      (70, 300, 5000, 3, 20, nat.MP_FLAG_FFT_FUSED), (33, 700, 9000, 2, 16, nat.MP_FLAG_FFT_FUSED),
                                      (16, 256, 8192, 1, 8, nat.MP_FLAG_FFT_FUSED), (97, 128, 700, 4, 12, nat.MP_FLAG_FFT_FUSED),
                                      (40, 1100, 3000, 2, 6, nat.MP_FLAG_FFT_FUSED)):
