@@ -124,7 +124,8 @@ int mp_profile_enable(int every);
                                      blocks that screen does not touch -- and refines their contenders -- meanwhile (1, default; 0: off) */
 #define MP_TUNE_LAZY_FORCE 16      /* TIMING EXPERIMENTS ONLY -- the events are WRONG while it is set: the launch-per-step lazy
                                      screen's tile masks are drawn at random (1.p: every (segment, tile) skipped with probability
-                                     p; 2.p: every segment skips all its tiles with probability p; 0, default: off).  How the
+                                     p; 2.p: every segment skips all its tiles with probability p; 0, default: off); refused unless the process has
+                                     MP_ALLOW_WRONG_RESULTS=1 in its environment.  How the
                                      screen's time follows the share and the pattern of skipped workgroups: DESIGN.md 4d       */
 #define MP_TUNE_CLEAR_MEMSET 15    /* debug: 1 = the encode's clears are hipMemsetAsync calls instead of one kernel launch (what a
                                      stream capture makes of memset nodes: scripts/graph_memset_repro.py); 0 (default) */

@@ -17,6 +17,7 @@
 //     conflict-free ds_read_b128; the residual window is read as a Toeplitz A-operand straight
 //     from LDS with ds_read_b32 at immediate offsets.
 #include <hip/hip_runtime.h>
+#include <cstdlib>
 #include <stdint.h>
 #include <stdio.h>
 #include <string.h>
@@ -1946,7 +1947,14 @@ int mp_tune(int key, double value) {
     if (key == MP_TUNE_LAZY_REUSE && value >= 0 && value <= 4) { persist_reuse.store((int)value); return MP_OK; }
     if (key == MP_TUNE_LAZY_RADIUS && value >= -1 && value <= 64) { persist_radius.store((int)value); return MP_OK; }
     if (key == MP_TUNE_PERSIST_PRESCAN && (value == 0 || value == 1)) { persist_prescan.store((int)value); return MP_OK; }
-    if (key == MP_TUNE_LAZY_FORCE && value >= 0 && value < 3) { lazy_force.store((float)value); return MP_OK; }
+    if (key == MP_TUNE_LAZY_FORCE && value >= 0 && value < 3) {
+        // (random tile masks: the events are WRONG while it is set -- a timing instrument, accepted only from a process that
+        //  says so in its environment, so that no product path can switch it on by accident)
+        const char *ok = getenv("MP_ALLOW_WRONG_RESULTS");
+        if (value > 0 && !(ok && ok[0] == '1')) return fail(MP_ERR_ARG, "mp_tune(MP_TUNE_LAZY_FORCE): set MP_ALLOW_WRONG_RESULTS=1 in the environment%s");
+        lazy_force.store((float)value);
+        return MP_OK;
+    }
     if (key == MP_TUNE_CLEAR_MEMSET && (value == 0 || value == 1)) { clear_with_memset.store((int)value); return MP_OK; }
     return fail(MP_ERR_ARG, "mp_tune: unknown key or bad value%s");
 }

@@ -354,3 +354,16 @@ def test_event_lists_are_lazy_and_equal_to_the_eager_structures():
     # an empty encode
     empty = mpm._EventStore(atom[:, :0], lag[:, :0], gain[:, :0], du, torch.device("cpu"), A)
     assert len(empty.instances()) == 0 and len(empty.flat()) == 0 and list(empty.flat()) == []
+
+
+def test_the_timing_only_knob_is_refused_without_its_environment_variable(monkeypatch):
+    """mp_tune(MP_TUNE_LAZY_FORCE) draws the lazy screen's tile masks at random -- an instrument for timing the screen
+    against the share and pattern of skipped workgroups; the events are wrong while it is set.  No product
+    path can switch it on: the library refuses it unless the process says MP_ALLOW_WRONG_RESULTS=1."""
+    monkeypatch.delenv("MP_ALLOW_WRONG_RESULTS", raising=False)
+    with pytest.raises(nat.NativeError):
+        nat.tune(nat.MP_TUNE_LAZY_FORCE, 1.5)
+    nat.tune(nat.MP_TUNE_LAZY_FORCE, 0)            # switching it OFF is always allowed
+    monkeypatch.setenv("MP_ALLOW_WRONG_RESULTS", "1")
+    nat.tune(nat.MP_TUNE_LAZY_FORCE, 1.5)
+    nat.tune(nat.MP_TUNE_LAZY_FORCE, 0)
