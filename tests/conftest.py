@@ -35,3 +35,19 @@ def oracle():
     import mp_oracle
     mp_oracle.build()
     return mp_oracle
+
+
+@pytest.fixture(autouse=True)
+def _library_knobs_back_to_their_defaults():
+    """mp_tune's knobs are process-wide (include/mpcore.h); tests that turn one share a process with every other test.
+    Whatever a test leaves behind -- by a failed assertion ahead of its own clean-up, too -- is reset here, so that no
+    test's result depends on which test ran before it."""
+    yield
+    from mpcore import _native as nat
+    if not os.path.exists(nat.LIB_PATH):
+        return
+    for key, default in ((nat.MP_TUNE_TAU, 0), (nat.MP_TUNE_SCREEN_PPS, 0), (nat.MP_TUNE_GROUPS, 4), (nat.MP_TUNE_AUDIT, 0),
+                         (nat.MP_TUNE_PERSIST_SHARDS, 0), (nat.MP_TUNE_PERSIST_WORKERS, 0), (nat.MP_TUNE_PERSIST_SELECTS, 0),
+                         (nat.MP_TUNE_LAZY_MARGIN, 0), (nat.MP_TUNE_LAZY_REUSE, 0), (nat.MP_TUNE_LAZY_RADIUS, 0),
+                         (nat.MP_TUNE_PERSIST_PRESCAN, 1), (nat.MP_TUNE_CLEAR_MEMSET, 0), (nat.MP_TUNE_LAZY_FORCE, 0)):
+        nat.tune(key, default)
