@@ -407,7 +407,15 @@ def cached_coherence(dict_unit, build_now=False):
         return None
 
 
-LAZY_MIN_BATCH = 24   # (the persistent form's threshold: below it the table would not be used)
+def lazy_pays(batch, n_atoms, n_steps):
+    """Is the lazy screen worth asking for (scripts/small_lazy.py, persistent form with / without the table)?  What it saves
+    is screen tasks, what it costs is ~1.2 us in every select: it pays where a step has many tile screens to shed -- 512 x 512
+    (16 tiles): -1 .. -4 % up to 16 segments, +4 % at 24, +30 % at 64; 1024 x 1024 (32 tiles of 4096-point tasks): +7 % at ONE
+    segment, +16 .. +32 % from four; dictionaries of one or two tiles (64 x 300, 16 x 256): -5 % at any batch."""
+    tiles = (int(n_atoms) + 31) // 32
+    return int(n_steps) >= 8 and tiles >= 4 and (tiles >= 32 or int(batch) * tiles >= 384)
+
+
 _tls = __import__("threading").local()   # .lazy: did this thread's last encode() hand the kernel a coherence table?
 
 
@@ -446,7 +454,7 @@ def encode(signal, dict_unit, n_steps, path=MP_PATH_INCREMENTAL, flags=0, want_r
                 residual[sl] = r
         _tls.lazy = any_lazy
         return atom, lag, gain, residual
-    if coherence is None and path == MP_PATH_FFT and not conv_model and B >= LAZY_MIN_BATCH and K >= 8 and \
+    if coherence is None and path == MP_PATH_FFT and not conv_model and lazy_pays(B, A, K) and \
             not (int(flags) & ~MP_FLAG_FFT_PERSISTENT):
         # a batch large enough for the table to pay for itself within this one call gets it at once, new dictionary or not:
         # the table is A * A / 2 transforms, the launch it trims B (K - 1) A / 2, of which a third go (512 atoms, 64 steps:
@@ -544,7 +552,7 @@ class EncodePlan:
         else:
             groups = max(2, min(4, int(sub_batches)))
         if lazy is None:
-            lazy = (groups == 0 and self.path == MP_PATH_FFT and int(batch) >= LAZY_MIN_BATCH and int(n_steps) >= 8 and
+            lazy = (groups == 0 and self.path == MP_PATH_FFT and lazy_pays(batch, A, n_steps) and
                     not (int(flags) & ~MP_FLAG_FFT_PERSISTENT))
         self.lazy = bool(lazy) and self.path == MP_PATH_FFT and lib().mp_coherence_workspace_bytes(A, L) > 0
         self._dict_copy = self._table = None

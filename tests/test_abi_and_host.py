@@ -367,3 +367,11 @@ def test_the_timing_only_knob_is_refused_without_its_environment_variable(monkey
     monkeypatch.setenv("MP_ALLOW_WRONG_RESULTS", "1")
     nat.tune(nat.MP_TUNE_LAZY_FORCE, 1.5)
     nat.tune(nat.MP_TUNE_LAZY_FORCE, 0)
+
+
+def test_when_the_mirror_asks_for_the_lazy_screen():
+    """_native.lazy_pays: by tile screens per step, not by batch alone (scripts/small_lazy.py)."""
+    assert nat.lazy_pays(64, 512, 64) and nat.lazy_pays(24, 512, 64) and not nat.lazy_pays(16, 512, 64)
+    assert nat.lazy_pays(1, 1024, 32) and nat.lazy_pays(128, 4096, 256)
+    assert not nat.lazy_pays(24, 64, 16) and not nat.lazy_pays(1000, 16, 8) and not nat.lazy_pays(1000, 64, 16)   # one or two tiles: never
+    assert not nat.lazy_pays(64, 512, 4)

@@ -676,7 +676,7 @@ def test_fixed_dictionary_gets_the_lazy_screen_through_the_api(oracle):
     from mpcore import _native as nat
     from mpcore import encode_packed, synth
     nat.clear_caches()
-    A, L, N, B, K = 64, 256, 6000, 30, 12
+    A, L, N, B, K = 256, 256, 6000, 48, 12        # (8 tiles x 48 segments: enough tile screens per step for the mirror to ask for the table, _native.lazy_pays)
     d_np = synth.make_dictionary(A, L, seed=5)
     d2_np = synth.make_dictionary(A, L, seed=55)
     x_np = synth.make_segments(B, N, d_np, n_events=20, seed=6)       # (each signal sparse in its own dictionary: the

@@ -889,6 +889,13 @@ def test_lazy_screen_is_bit_identical_to_the_oracle(oracle):
         # the automatic form: a dictionary that comes again with the same CONTENT gets its table (remembered at the first
         # call, seen equal at the second, table from the third); a flag that names another form does not
         nat.clear_caches()
+        A, L, N, B, K = 256, 256, 6000, 48, 12        # (a shape the mirror asks for the table by itself: _native.lazy_pays)
+        d = synth.make_dictionary(A, L, seed=7 + A)
+        du_np = oracle.unit_norm(d)
+        du = torch.from_numpy(du_np).to(DEV)
+        x_host = synth.make_segments(B, N, d, n_events=2 * K, seed=9 + B)
+        want = oracle.encode(x_host, du_np, K)
+        x = torch.from_numpy(x_host).to(DEV)
         for call in range(2):
             nat.encode(x, du, K, path=nat.MP_PATH_FFT)
             torch.cuda.synchronize()
@@ -1048,7 +1055,7 @@ def test_plan_replayed_after_an_in_place_dictionary_update(oracle):
     `.data`, which no version counter sees -- runs with an infinite table (every tile screened) and still returns the
     oracle's events for the NEW dictionary; after refresh_dictionary() replays skip transforms again.  The table does
     not belong to any cache (clear_caches() between replays changes nothing)."""
-    A, L, N, B, K = 64, 256, 6000, 40, 12
+    A, L, N, B, K = 256, 256, 6000, 48, 12        # (enough tile screens per step for a plan to take the lazy screen by itself)
     d1, d2 = synth.make_dictionary(A, L, seed=161), synth.make_dictionary(A, L, seed=162)
     du1, du2 = oracle.unit_norm(d1), oracle.unit_norm(d2)
     # (each dictionary has more planted events in the mix than the run has steps: the lazy screen's floor -- the
