@@ -127,6 +127,9 @@ int mp_profile_enable(int every);
                                      p; 2.p: every segment skips all its tiles with probability p; 0, default: off); refused unless the process has
                                      MP_ALLOW_WRONG_RESULTS=1 in its environment.  How the
                                      screen's time follows the share and the pattern of skipped workgroups: DESIGN.md 4d       */
+#define MP_TUNE_LAZY_COMPACT 17    /* launch-per-step lazy screen: 1 (default) = a masked screen launch runs from the masks' compacted work list
+                                     (one small kernel per step builds it); 0 = every workgroup of the full grid looks its mask up and
+                                     returns if it is set.  Same results either way                                              */
 #define MP_TUNE_CLEAR_MEMSET 15    /* debug: 1 = the encode's clears are hipMemsetAsync calls instead of one kernel launch (what a
                                      stream capture makes of memset nodes: scripts/graph_memset_repro.py); 0 (default) */
 int mp_tune(int key, double value);

@@ -1129,6 +1129,7 @@ struct Workspace {
     cpx *xrec;      // ... and the per-(segment, step) window records
     unsigned *skip; // lazy screen, launch-per-step form: [B][4] tile masks (select -> next screen launch)
     float *lfloor;  // ... and the run's floor per segment [B] (persist_floor_*_kernel after step 0)
+    unsigned *work; // ... and the compacted list of (segment, tile) screens the masks leave, tile-major: [B * (NAT + 1)] (count first)
     size_t bytes;
 };
 
@@ -1159,6 +1160,7 @@ Workspace carve(const Geom &g, int path, char *base, int K = 0) {
     w.xrec = nullptr;
     w.skip = nullptr;
     w.lfloor = nullptr;
+    w.work = nullptr;
     if (path == MP_PATH_FFT) {
         FftGeom f;
         if (make_fft_geom(g, &f)) {
@@ -1180,6 +1182,7 @@ Workspace carve(const Geom &g, int path, char *base, int K = 0) {
             size_t o_sk = take(quarters ? (size_t)g.B * g.NBLK * g.NAT * SUBCELLS * sizeof(float) : 0);
             size_t o_lz = take((size_t)g.B * 4 * sizeof(unsigned));
             size_t o_lf = take((size_t)g.B * sizeof(float));
+            size_t o_wk = take(g.NAT <= 128 ? (size_t)g.B * (g.NAT + 1) * sizeof(unsigned) : 0);
             w.tw = reinterpret_cast<cpx *>(base + o_tw);
             w.pspec = reinterpret_cast<cpx *>(base + o_ps);
             w.xspec = reinterpret_cast<cpx *>(base + o_xs);
@@ -1194,6 +1197,7 @@ Workspace carve(const Geom &g, int path, char *base, int K = 0) {
             if (quarters) w.subk = reinterpret_cast<float *>(base + o_sk);
             w.skip = reinterpret_cast<unsigned *>(base + o_lz);
             w.lfloor = reinterpret_cast<float *>(base + o_lf);
+            if (g.NAT <= 128) w.work = reinterpret_cast<unsigned *>(base + o_wk);
             // persistent schedule (mppersist.inc): queue + one window record per (segment, step >= 2)
             // (one write-once window record per segment and step: not for batches whose records would pass 2 GiB --
             //  those run launch per step)
@@ -1613,22 +1617,27 @@ int fft_iteration(const Geom &g, const Workspace &w, const float *du, int K, int
                 // pair spectra that cannot stay in the L2s: segment-fastest grid order (see the kernel)
                 const bool seg_fast = (size_t)g.NAT * f.NPT * f.M * sizeof(cpx) > (size_t)16 << 20;
                 const unsigned gwp = nw * (16 / (C::SLOTS * pps));
-                const dim3 grid = seg_fast ? dim3((unsigned)g.B, gwp, g.NAT) : dim3(gwp, g.NAT, (unsigned)g.B);
+                // (masked launches, lazy form: the select's masks compacted into a work list -- the same (B, parts, tiles)
+                //  grid, entry x + B z each; mplazy.inc: lazy_compact_kernel)
+                const bool listed = lazy_form && k >= 2 && w.work != nullptr && g.B <= 65535 &&
+                                    lazy_compact.load(std::memory_order_relaxed) != 0;
+                const dim3 grid = (seg_fast || listed) ? dim3((unsigned)g.B, gwp, g.NAT) : dim3(gwp, g.NAT, (unsigned)g.B);
                 if (flags & MP_FLAG_INTERNAL_COHERENCE) {   // mp_coherence_f32: cell maxima of |correlation|, nothing after the screen
                     constexpr int LC = LS <= 13 ? LS : 13;  // (coherence_geom: 1024- to 8192-point transforms)
                     auto kabs = (fft_screen_kernel<LC, true>);
                     if ((rc = fft_lds_attr(kabs, lds_s))) return rc;
                     hipLaunchKernelGGL(kabs, grid, dim3(C::WG), lds_s, st, w.xspec, w.pspec, w.tw, dirty, w.wnorm, w.keys, w.ceps,
                                        g.N, g.A, g.NBLK, g.NAT, f.V, f.NW, tau, pps, (int)seg_fast, (float *)nullptr,
-                                       (unsigned *)nullptr, (const unsigned *)nullptr);
+                                       (unsigned *)nullptr, (const unsigned *)nullptr, (const unsigned *)nullptr);
                     HIP_TRY(hipGetLastError());
                     g_prof.end(st);
                     return MP_OK;
                 }
                 if ((rc = fft_lds_attr(fft_screen_kernel<LS>, lds_s))) return rc;
                 hipLaunchKernelGGL(fft_screen_kernel<LS>, grid, dim3(C::WG), lds_s, st, w.xspec, w.pspec, w.tw, dirty,
-                                   w.wnorm, w.keys, w.ceps, g.N, g.A, g.NBLK, g.NAT, f.V, f.NW, tau, pps, (int)seg_fast, subk, bsum,
-                                   (const unsigned *)(lazy_form && k >= 2 ? w.skip : nullptr));
+                                   w.wnorm, w.keys, w.ceps, g.N, g.A, g.NBLK, g.NAT, f.V, f.NW, tau, pps, (int)(seg_fast || listed), subk, bsum,
+                                   (const unsigned *)(lazy_form && k >= 2 ? w.skip : nullptr),
+                                   (const unsigned *)(listed ? w.work : nullptr));
             } else {
                 hipLaunchKernelGGL(fft_correlate_kernel<LG>, dim3(nw, g.NAT, (unsigned)g.B), dim3(256), lds, st,
                                    w.xspec, w.pspec, w.tw, dirty, w.wnorm, w.keys, w.ceps, g.N, g.A, g.NBLK,
@@ -1668,6 +1677,8 @@ int fft_iteration(const Geom &g, const Workspace &w, const float *du, int K, int
                                    lazy_form && k >= 1 ? lz.mu : (const float *)nullptr, tau, lz.margin, lz.reuse,
                                    (const float *)w.lfloor, lazy_form && k >= 1 ? w.skip : (unsigned *)nullptr, lz.force);
             })
+            if (lazy_form && k >= 1 && k + 1 < K && w.work != nullptr && g.B <= 65535 && lazy_compact.load(std::memory_order_relaxed) != 0)
+                hipLaunchKernelGGL(lazy_compact_kernel, dim3(1), dim3(1024), 0, st, (const unsigned *)w.skip, (int)g.B, g.NAT, w.work);
             if (lazy_form && k == 0 && K > 2) {
                 // the lazy screen's floor: where this run's maxima are expected to end -- the (K + K/16 + 1)-th largest peak
                 // among the CELLS after step 0's select (mplazy.inc: lazy_floor_cells_kernel; peaks dominate their own
@@ -1834,6 +1845,7 @@ Workspace sub_batch(const Workspace &w, const Geom &g, int path, int64_t b0, int
         v.bsum = w.bsum + b0 * g.NBLK * 2;
         if (w.skip) v.skip = w.skip + b0 * 4;
         if (w.lfloor) v.lfloor = w.lfloor + b0;
+        if (w.work) v.work = w.work + (size_t)b0 * (g.NAT + 1);   // (each sub-batch its own list: its count, then up to n * NAT entries)
     }
     return v;
 }
@@ -1956,6 +1968,7 @@ int mp_tune(int key, double value) {
         return MP_OK;
     }
     if (key == MP_TUNE_CLEAR_MEMSET && (value == 0 || value == 1)) { clear_with_memset.store((int)value); return MP_OK; }
+    if (key == MP_TUNE_LAZY_COMPACT && (value == 0 || value == 1)) { lazy_compact.store((int)value); return MP_OK; }
     return fail(MP_ERR_ARG, "mp_tune: unknown key or bad value%s");
 }
 

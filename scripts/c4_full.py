@@ -35,6 +35,9 @@ if os.environ.get("C4_FORCE"):  # TIMING ONLY: random tile masks (1.p per tile, 
     os.environ["MP_ALLOW_WRONG_RESULTS"] = "1"
     nat.tune(nat.MP_TUNE_LAZY_FORCE, float(os.environ["C4_FORCE"]))
     print(f"forced random skip masks {os.environ['C4_FORCE']} (results invalid)", flush=True)
+if os.environ.get("C4_COMPACT"):  # 0: masked screens exit per workgroup instead of running from the compacted work list
+    nat.tune(nat.MP_TUNE_LAZY_COMPACT, int(os.environ["C4_COMPACT"]))
+    print(f"compacted work list: {os.environ['C4_COMPACT']}", flush=True)
 if os.environ.get("C4_TUNE"):   # "margin,reuse": how the screen's time follows the share of tiles skipped
     mg, ru = os.environ["C4_TUNE"].split(",")
     nat.tune(nat.MP_TUNE_LAZY_MARGIN, float(mg)); nat.tune(nat.MP_TUNE_LAZY_REUSE, int(ru))

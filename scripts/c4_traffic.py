@@ -19,7 +19,9 @@ if os.environ.get("C4_LAZY") or os.environ.get("C4_FORCE"):   # the lazy screen 
     co = nat.coherence_table(du)
     if os.environ.get("C4_FORCE"):
         os.environ["MP_ALLOW_WRONG_RESULTS"] = "1"
-    nat.tune(nat.MP_TUNE_LAZY_FORCE, float(os.environ["C4_FORCE"]))
+        nat.tune(nat.MP_TUNE_LAZY_FORCE, float(os.environ["C4_FORCE"]))
+    if os.environ.get("C4_COMPACT"):   # 0: masked screens exit per workgroup instead of running from the compacted work list
+        nat.tune(nat.MP_TUNE_LAZY_COMPACT, int(os.environ["C4_COMPACT"]))
     if os.environ.get("C4_TUNE"):
         mg, ru = os.environ["C4_TUNE"].split(",")
         nat.tune(nat.MP_TUNE_LAZY_MARGIN, float(mg)); nat.tune(nat.MP_TUNE_LAZY_REUSE, int(ru))

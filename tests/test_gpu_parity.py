@@ -923,8 +923,9 @@ def test_lazy_screen_is_bit_identical_to_the_oracle(oracle):
 def test_lazy_screen_of_the_launch_per_step_form_is_bit_identical_to_the_oracle(oracle):
     """Shapes the persistent form does not take (more than 16384 cells per segment; 8192-point transforms as BASELINE
     configs[3] has them) run launch per step with the fused whole-cell select -- and, given the coherence table, with the
-    lazy screen in THAT form: the select leaves a tile mask, the next screen launch's workgroups of those tiles leave at
-    once (csrc/mpfft.inc: fft_select_fused_kernel / fft_screen_kernel).  Same events as the oracle, bit for bit, at any
+    lazy screen in THAT form: the select leaves a tile mask, the next screen launch runs from the masks' compacted work
+    list -- or, compaction off, its workgroups of those tiles leave at once (csrc/mpfft.inc: fft_select_fused_kernel /
+    fft_screen_kernel; csrc/mplazy.inc: lazy_compact_kernel).  Same events as the oracle, bit for bit, at any
     margin; tiles really are skipped; without the table nothing is."""
     try:
         # (17 600 cells per segment with short atoms: the fused select by its size once the one-launch form is declined; 8192-point
@@ -948,7 +949,9 @@ def test_lazy_screen_of_the_launch_per_step_form_is_bit_identical_to_the_oracle(
             assert nat.last_schedule() == 1 and nat.lazy_stats()["decided"] == 0
             for name, t in zip(("atom", "lag", "gain", "residual"), plain):
                 assert np.array_equal(t.cpu().numpy(), want[name]), (A, L, "plain", name)
-            for margin in (1.0, 0.7, 0.3):
+            for margin in (1.0, 0.7, 0.3, -0.7):   # (negative: margin 0.7 with the masked screens NOT run from a compacted
+                nat.tune(nat.MP_TUNE_LAZY_COMPACT, int(margin > 0))   # work list -- every workgroup looks its mask up and leaves)
+                margin = abs(margin)
                 nat.tune(nat.MP_TUNE_LAZY_MARGIN, margin)
                 a, l, g, r = nat.encode(x, du, K, path=nat.MP_PATH_FFT, flags=flags, coherence=mu)
                 torch.cuda.synchronize()
@@ -961,6 +964,7 @@ def test_lazy_screen_of_the_launch_per_step_form_is_bit_identical_to_the_oracle(
                     assert np.array_equal(t.cpu().numpy()[keep], want[name][keep]), (A, L, margin, name)
     finally:
         nat.tune(nat.MP_TUNE_LAZY_MARGIN, 0)
+        nat.tune(nat.MP_TUNE_LAZY_COMPACT, 1)
 
 
 def test_persistent_form_with_scarce_and_odd_worker_counts(oracle):
