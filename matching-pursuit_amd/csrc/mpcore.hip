@@ -1261,6 +1261,10 @@ int launch_correlate_t(const Geom &g, const Workspace &w, const int *dirty, floa
     return MP_OK;
 }
 
+// 1-D grid for a launch whose workgroups are dealt to the XCDs by hand (workgroup i runs on XCD i mod 8; mpfft.inc:
+// fft_screen_kernel): `units` groups of `per` workgroups each, a whole group on one XCD.
+inline unsigned xcd_grid(int64_t per, int64_t units) { return (unsigned)(8 * per * ((units + 7) / 8)); }
+
 int num_cus() {
     static std::atomic<int> cus[MAX_DEVICES];  // zero-initialised; racing first calls compute the same value
     std::atomic<int> &slot = cus[current_device()];
@@ -1592,11 +1596,11 @@ int fft_iteration(const Geom &g, const Workspace &w, const float *du, int K, int
             const size_t lds_s = ((size_t)C::SLOTS * C::M + C::M / 64 + 64) * sizeof(cpx);
             const bool seg_fast = (size_t)g.NAT * f.NPT * f.M * sizeof(cpx) > (size_t)16 << 20;
             const unsigned gwp = nw * (16 / (C::SLOTS * pps));
-            const dim3 grid = seg_fast ? dim3((unsigned)g.B, gwp, g.NAT) : dim3(gwp, g.NAT, (unsigned)g.B);
+            const dim3 grid = seg_fast ? dim3(xcd_grid(g.B, (int64_t)gwp * g.NAT)) : dim3(gwp, g.NAT, (unsigned)g.B);
             if ((rc = fft_lds_attr(fft_screen_split_kernel<SPLIT_LOGH>, lds_s))) return rc;
             hipLaunchKernelGGL(fft_screen_split_kernel<SPLIT_LOGH>, grid, dim3(C::WG), lds_s, st, w.xspec, w.pspec,
                                w.tw, dirty, w.wnorm, w.keys, w.ceps, g.N, g.A, g.NBLK, g.NAT, f.V, f.NW, tau, pps,
-                               (int)seg_fast);
+                               seg_fast ? (int)g.B : 0);
         } else if (f.split) {
             hipLaunchKernelGGL(fft_correlate_split_kernel<SPLIT_LOGH>, dim3(2 * nw, g.NAT, (unsigned)g.B), dim3(256), lds, st,
                                w.xspec, w.pspec, w.tw, dirty, w.wnorm, w.keys, w.ceps, g.N, g.A, g.NBLK, g.NAT, f.V,
@@ -1617,17 +1621,18 @@ int fft_iteration(const Geom &g, const Workspace &w, const float *du, int K, int
                 // pair spectra that cannot stay in the L2s: segment-fastest grid order (see the kernel)
                 const bool seg_fast = (size_t)g.NAT * f.NPT * f.M * sizeof(cpx) > (size_t)16 << 20;
                 const unsigned gwp = nw * (16 / (C::SLOTS * pps));
-                // (masked launches, lazy form: the select's masks compacted into a work list -- the same (B, parts, tiles)
-                //  grid, entry x + B z each; mplazy.inc: lazy_compact_kernel)
+                // (masked launches, lazy form: the select's masks compacted into a work list -- room for every (segment,
+                //  tile) entry, chunks of 16 entries x parts dealt to the XCDs; mplazy.inc: lazy_compact_kernel)
                 const bool listed = lazy_form && k >= 2 && w.work != nullptr && g.B <= 65535 &&
                                     lazy_compact.load(std::memory_order_relaxed) != 0;
-                const dim3 grid = (seg_fast || listed) ? dim3((unsigned)g.B, gwp, g.NAT) : dim3(gwp, g.NAT, (unsigned)g.B);
+                const dim3 grid = listed ? dim3(xcd_grid(16 * (int64_t)gwp, ((int64_t)g.B * g.NAT + 15) / 16))
+                                  : seg_fast ? dim3(xcd_grid(g.B, (int64_t)gwp * g.NAT)) : dim3(gwp, g.NAT, (unsigned)g.B);
                 if (flags & MP_FLAG_INTERNAL_COHERENCE) {   // mp_coherence_f32: cell maxima of |correlation|, nothing after the screen
                     constexpr int LC = LS <= 13 ? LS : 13;  // (coherence_geom: 1024- to 8192-point transforms)
                     auto kabs = (fft_screen_kernel<LC, true>);
                     if ((rc = fft_lds_attr(kabs, lds_s))) return rc;
                     hipLaunchKernelGGL(kabs, grid, dim3(C::WG), lds_s, st, w.xspec, w.pspec, w.tw, dirty, w.wnorm, w.keys, w.ceps,
-                                       g.N, g.A, g.NBLK, g.NAT, f.V, f.NW, tau, pps, (int)seg_fast, (float *)nullptr,
+                                       g.N, g.A, g.NBLK, g.NAT, f.V, f.NW, tau, pps, seg_fast ? (int)g.B : 0, (float *)nullptr,
                                        (unsigned *)nullptr, (const unsigned *)nullptr, (const unsigned *)nullptr);
                     HIP_TRY(hipGetLastError());
                     g_prof.end(st);
@@ -1635,7 +1640,7 @@ int fft_iteration(const Geom &g, const Workspace &w, const float *du, int K, int
                 }
                 if ((rc = fft_lds_attr(fft_screen_kernel<LS>, lds_s))) return rc;
                 hipLaunchKernelGGL(fft_screen_kernel<LS>, grid, dim3(C::WG), lds_s, st, w.xspec, w.pspec, w.tw, dirty,
-                                   w.wnorm, w.keys, w.ceps, g.N, g.A, g.NBLK, g.NAT, f.V, f.NW, tau, pps, (int)(seg_fast || listed), subk, bsum,
+                                   w.wnorm, w.keys, w.ceps, g.N, g.A, g.NBLK, g.NAT, f.V, f.NW, tau, pps, seg_fast ? (int)g.B : 0, subk, bsum,
                                    (const unsigned *)(lazy_form && k >= 2 ? w.skip : nullptr),
                                    (const unsigned *)(listed ? w.work : nullptr));
             } else {
