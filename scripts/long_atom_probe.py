@@ -7,6 +7,8 @@ import numpy as np, torch
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "matching-pursuit_amd"))
 from mpcore import _native as nat, synth
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 8
+FLAGS = int(sys.argv[2]) if len(sys.argv) > 2 else 0   # e.g. MP_FLAG_REFINE_MFMA
+print("flags", FLAGS, flush=True)
 K = 32
 for N in (8192, 16384, 32768):
     A, L = 1024, N // 4
@@ -16,11 +18,11 @@ for N in (8192, 16384, 32768):
     for kind, xh in (("planted", synth.make_segments(B, N, d, n_events=48, seed=N)),
                      ("noise", rng.standard_normal((B, N)).astype(np.float32))):
         x = torch.from_numpy(xh).cuda()
-        nat.encode(x, du, K, path=nat.MP_PATH_FFT); torch.cuda.synchronize()
+        nat.encode(x, du, K, path=nat.MP_PATH_FFT, flags=FLAGS); torch.cuda.synchronize()
         for every in (0, 1):
             nat.profile_enable(every); nat.profile_read()
             t0 = time.perf_counter()
-            out = nat.encode(x, du, K, path=nat.MP_PATH_FFT)
+            out = nat.encode(x, du, K, path=nat.MP_PATH_FFT, flags=FLAGS)
             torch.cuda.synchronize()
             dt = time.perf_counter() - t0
             p = nat.profile_read()
