@@ -1576,7 +1576,7 @@ int fft_iteration(const Geom &g, const Workspace &w, const float *du, int K, int
         const int nw = k == 0 ? f.NW : 1;
         g_prof.begin(PROF_SELECT, st);
         if (f.split) {
-            hipLaunchKernelGGL(fft_window_split_kernel<SPLIT_LOGH>, dim3(nw, (unsigned)g.B, 2), dim3(256), lds, st, w.res,
+            hipLaunchKernelGGL(fft_window_split_kernel<SPLIT_LOGH>, dim3(nw, (unsigned)g.B, 2), dim3(1024), lds, st, w.res,
                                g.Ns, dirty, w.tw, w.xspec, w.wnorm, f.V, f.NW, (const float *)w.dscale);
         } else if (k == 0 || !fused_tail) {
             MP_FFT_DISPATCH(f.logM, {
