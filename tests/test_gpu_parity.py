@@ -532,6 +532,50 @@ def test_long_atom_split_transforms_planted_events_and_extreme_amplitudes(oracle
         assert all(torch.equal(a, b) for a, b in zip(out, ref))
 
 
+def test_four_kernel_refine_with_many_contenders_is_bit_identical(oracle):
+    """The stand-alone refine kernel of the four-kernel form (csrc/mpfft.inc: fft_refine_valu_kernel -- 16 x 16 x 4 matrix-core
+    chains, 16 atoms per workgroup, a segment's contenders side by side) on inputs that give it many contenders per
+    select: plain noise against long atoms (the screen's bound grows with the atom length), atom counts that leave the
+    second workgroup of a cell with no atoms at all / a partly filled tile, chunks of 512 taps with a ragged last one --
+    split transforms (L > 5398), an unsplit size reached with MP_FLAG_FFT_UNFUSED, and 512-point transforms (where the
+    four-kernel form is the only one).  Bitwise against the oracle; some contenders must have been refined."""
+    rng = np.random.default_rng(77)
+    for A, L, N, B, K, flags in ((5, 5500, 9000, 2, 4, 0), (37, 6001, 7000, 3, 3, 0), (19, 2300, 6000, 2, 5, nat.MP_FLAG_FFT_UNFUSED),
+                                 (50, 100, 3000, 3, 6, nat.MP_FLAG_FFT_NO_PERSISTENT), (16, 700, 4000, 9, 4, nat.MP_FLAG_FFT_UNFUSED)):
+        du = oracle.unit_norm(synth.make_dictionary(A, L, seed=A + L))
+        x = rng.standard_normal((B, N)).astype(np.float32)
+        want = oracle.encode(x, du, K)
+        atom, lag, gain, res = _gpu_encode(x, du, K, nat.MP_PATH_FFT, flags)
+        keep = ~np.isnan(gain).any(axis=1)      # (more than 32 contenders: marked in-band, re-encoded by the caller)
+        assert keep.sum() >= B - 1, (A, L)
+        assert np.array_equal(atom[keep], want["atom"][keep]) and np.array_equal(lag[keep], want["lag"][keep]), (A, L)
+        assert np.array_equal(gain[keep], want["gain"][keep]) and np.array_equal(res[keep], want["residual"][keep]), (A, L)
+
+
+@pytest.mark.parametrize("B", [1, 3, 9, 17])
+def test_xcd_aware_screen_grid_with_odd_batch_sizes(oracle, B):
+    """Dictionaries whose pair spectra exceed the L2s (> 16 MB) are screened on a 1-D grid dealt to the XCDs by hand
+    (csrc/mpfft.inc: fft_screen_kernel, seg_fast = B: workgroup i -> XCD i mod 8, unit (i / 8 / B) * 8 + XCD, segment rotated
+    by the unit): batch sizes that are not multiples of 8, a unit count (tiles x parts) that is not one either, full and
+    incremental launches, with and without the lazy screen's compacted work list -- every (segment, unit) must be screened
+    exactly once.  Bitwise against the oracle."""
+    A, L, N, K = 2080, 1100, 5000, 5     # 65 tiles of 4096-point transforms: 34 MB of pair spectra
+    d = synth.make_dictionary(A, L, seed=5)
+    du_np = oracle.unit_norm(d)
+    x = synth.make_segments(B, N, d, n_events=10, seed=6 + B)
+    want = oracle.encode(x, du_np, K)
+    du = torch.from_numpy(du_np).to(DEV)
+    xd = torch.from_numpy(x).to(DEV)
+    mu = nat.coherence_table(du)
+    for flags, co in ((nat.MP_FLAG_FFT_NO_PERSISTENT, False), (nat.MP_FLAG_FFT_FUSED, False), (nat.MP_FLAG_FFT_FUSED, mu),
+                      (nat.MP_FLAG_FFT_FUSED | nat.MP_FLAG_NO_OVERLAP, mu)):
+        a, l, g, r = nat.encode(xd, du, K, path=nat.MP_PATH_FFT, flags=flags, coherence=co)
+        torch.cuda.synchronize()
+        assert nat.last_schedule() != -1
+        for name, t in zip(("atom", "lag", "gain", "residual"), (a, l, g, r)):
+            assert np.array_equal(t.cpu().numpy(), want[name]), (B, flags, name)
+
+
 def test_two_host_threads_encode_concurrently(oracle):
     """The header promises re-entrancy per stream (thread-local error string, stream pool and launch state; no
     other mutable globals outside the opt-in profiler): two host threads, each on its own torch stream, encode
