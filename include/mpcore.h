@@ -127,6 +127,10 @@ int mp_profile_enable(int every);
                                      p; 2.p: every segment skips all its tiles with probability p; 0, default: off); refused unless the process has
                                      MP_ALLOW_WRONG_RESULTS=1 in its environment.  How the
                                      screen's time follows the share and the pattern of skipped workgroups: DESIGN.md 4d       */
+#define MP_TUNE_PERSIST_FINE 18    /* persistent form: how a tile quarter's four atom pairs are walked -- 1 = by one slot of a workgroup (a task is
+                                     four transforms long), 2 = by two neighbouring slots, two pairs each (twice the tasks, half as
+                                     long: what small batches want), 0 (default) = 2 while every finer task still finds a workgroup
+                                     of its own.  Same results either way; 4096-point transforms have one slot per workgroup       */
 #define MP_TUNE_LAZY_COMPACT 17    /* launch-per-step lazy screen: 1 (default) = a masked screen launch runs from the masks' compacted work list
                                      (one small kernel per step builds it); 0 = every workgroup of the full grid looks its mask up and
                                      returns if it is set.  Same results either way                                              */

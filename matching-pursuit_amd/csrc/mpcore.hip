@@ -1977,6 +1977,7 @@ int mp_tune(int key, double value) {
     }
     if (key == MP_TUNE_CLEAR_MEMSET && (value == 0 || value == 1)) { clear_with_memset.store((int)value); return MP_OK; }
     if (key == MP_TUNE_LAZY_COMPACT && (value == 0 || value == 1)) { lazy_compact.store((int)value); return MP_OK; }
+    if (key == MP_TUNE_PERSIST_FINE && value >= 0 && value <= 2) { persist_fine.store((int)value); return MP_OK; }
     return fail(MP_ERR_ARG, "mp_tune: unknown key or bad value%s");
 }
 

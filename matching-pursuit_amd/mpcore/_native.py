@@ -35,6 +35,7 @@ MP_TUNE_LAZY_REUSE = 12
 MP_TUNE_LAZY_RADIUS = 13
 MP_TUNE_PERSIST_PRESCAN = 14
 MP_TUNE_CLEAR_MEMSET = 15
+MP_TUNE_PERSIST_FINE = 18 # persistent form: 1 = one slot per tile quarter, 2 = two slots (finer tasks), 0 = by load
 MP_TUNE_LAZY_COMPACT = 17 # launch-per-step lazy screen: masked launches from a compacted work list (1, default) or early exits (0)
 MP_TUNE_LAZY_FORCE = 16   # timing experiments only: random tile masks, wrong events
 MP_FLAG_GROUPS_SHIFT = 20

@@ -50,5 +50,5 @@ def _library_knobs_back_to_their_defaults():
                          (nat.MP_TUNE_PERSIST_SHARDS, 0), (nat.MP_TUNE_PERSIST_WORKERS, 0), (nat.MP_TUNE_PERSIST_SELECTS, 0),
                          (nat.MP_TUNE_LAZY_MARGIN, 0), (nat.MP_TUNE_LAZY_REUSE, 0), (nat.MP_TUNE_LAZY_RADIUS, 0),
                          (nat.MP_TUNE_PERSIST_PRESCAN, 1), (nat.MP_TUNE_CLEAR_MEMSET, 0), (nat.MP_TUNE_LAZY_FORCE, 0),
-                         (nat.MP_TUNE_LAZY_COMPACT, 1)):
+                         (nat.MP_TUNE_LAZY_COMPACT, 1), (nat.MP_TUNE_PERSIST_FINE, 0)):
         nat.tune(key, default)

@@ -1038,6 +1038,35 @@ def test_persistent_form_with_scarce_and_odd_worker_counts(oracle):
         nat.tune(nat.MP_TUNE_PERSIST_SHARDS, 0)
 
 
+def test_persistent_form_with_one_and_two_slots_per_tile_quarter(oracle):
+    """The persistent form's screen tasks come in two sizes (mp_tune(MP_TUNE_PERSIST_FINE): a tile quarter's four atom pairs
+    walked by one slot of the workgroup, or by two neighbouring slots whose maxima are merged in LDS -- the default for
+    small batches): both bit-identical to the oracle at 1024- and 2048-point transforms, with and without the lazy
+    screen, odd atom counts included (a second slot with nothing but dead pairs)."""
+    try:
+        for A, L, N, B, K in ((70, 300, 5000, 5, 9), (33, 200, 3000, 40, 6), (131, 512, 9000, 3, 12)):
+            d = synth.make_dictionary(A, L, seed=A)
+            du_np = oracle.unit_norm(d)
+            x_host = synth.make_segments(B, N, d, n_events=2 * K, seed=B)
+            want = oracle.encode(x_host, du_np, K)
+            du = torch.from_numpy(du_np).to(DEV)
+            x = torch.from_numpy(x_host).to(DEV)
+            mu = nat.coherence_table(du)
+            for fine in (1, 2):
+                nat.tune(nat.MP_TUNE_PERSIST_FINE, fine)
+                for co in (False, mu):
+                    a, l, g, r = nat.encode(x, du, K, path=nat.MP_PATH_FFT, flags=nat.MP_FLAG_FFT_PERSISTENT, coherence=co)
+                    torch.cuda.synchronize()
+                    st = nat.persist_stats()
+                    assert nat.last_schedule() == -1 and st["error"] == 0 and st["finished"] == B, (A, fine, st)
+                    keep = ~torch.isnan(g).any(dim=1).cpu().numpy()
+                    assert keep.sum() >= B - 1
+                    for name, t in zip(("atom", "lag", "gain", "residual"), (a, l, g, r)):
+                        assert np.array_equal(t.cpu().numpy()[keep], want[name][keep]), (A, fine, name)
+    finally:
+        nat.tune(nat.MP_TUNE_PERSIST_FINE, 0)
+
+
 def test_two_threads_run_the_persistent_form_concurrently(oracle):
     """Two persistent launches at the same time, from two host threads on two streams: each is sized for the whole
     GPU, so their workgroups share it -- whichever are resident draw the tickets; nobody waits for a particular
