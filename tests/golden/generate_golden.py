@@ -93,16 +93,21 @@ ENCODE_CASES = [
     ("mid_64x128_n4096_b3_k16", 64, 128, 4096, 3, 16, 12, 202),
     ("ragged_24x100_n1000_b2_k12", 24, 100, 1000, 2, 12, 8, 303),  # nothing a power of two
     ("c2shape_512x512_n32768_b2_k12", 512, 512, 32768, 2, 12, 36, 404),  # configs[1] shape
+    # atoms beyond 5398 samples (the multiband model's longest band has 8192): here every transform of the FFT schedule
+    # is split in two halves and the four-kernel select form refines on the matrix core
+    ("long_6x6000_n14000_b2_k5", 6, 6000, 14000, 2, 5, 6, 707),
 ]
 
 
-def main():
+def main(only=None):
     torch.manual_seed(0)
     torch.set_num_threads(8)
     mp, conv, norm, stft_mod, itns = load_reference()
     report = []
 
     for name, A, L, N, B, K, n_ev, seed in ENCODE_CASES:
+        if only is not None and name != only:
+            continue
         d = synth.make_dictionary(A, L, seed=seed)
         x = synth.make_segments(B, N, d, n_events=n_ev, seed=seed)
         sig = torch.from_numpy(x)[:, None, :]
@@ -125,6 +130,9 @@ def main():
         np.savez_compressed(os.path.join(HERE, f"encode_{name}.npz"), **small)
         report.append((name, float(gap.min()), rdb.tolist(),
                        bool((out["atom"] == out_fft["atom"]).all() and (out["lag"] == out_fft["lag"]).all())))
+    if only is not None:   # (python generate_golden.py encode <name>: one encode case, nothing else)
+        print(report)
+        return
 
     # dictionary_learning_step (:348-419)
     for name, A, L, N, B, K, n_ev, seed in [("dl_32x64_n2048_b4_k10", 32, 64, 2048, 4, 10, 10, 505),
@@ -511,6 +519,8 @@ if __name__ == "__main__":
         torch.set_num_threads(8)
         _mp, _conv, _norm, _stft, _ns = load_reference()
         lcn_fixtures(_mp, _norm)
+    elif len(sys.argv) > 2 and sys.argv[1] == "encode":  # one case of ENCODE_CASES
+        main(only=sys.argv[2])
     elif len(sys.argv) > 1 and sys.argv[1] == "c4":  # only the configs[3]-shape encode (minutes of CPU)
         torch.manual_seed(0)
         torch.set_num_threads(8)
