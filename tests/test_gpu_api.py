@@ -757,3 +757,19 @@ def test_sparse_helpers_on_the_device_match_reference(golden_dir):
     v, i = flat.max(dim=-1)
     assert torch.equal(sp1.reshape(x3.shape[0], -1).gather(1, i[:, None])[:, 0], v)
     assert int((sp1 != 0).sum()) == x3.shape[0] and packed1.shape[1] == 1 and onehot1.shape[1] == 1
+
+
+def test_dictionary_learning_loop_of_the_reference_experiment_converges():
+    """examples/dictionary_learning_loop.py -- the loop of experiments/archive/e_2023_7_14/experiment.py:33-41 (sparse_code with
+    flatten=True, scatter, dictionary_learning_step, `d[:] = new_d`) on synthetic audio, through the names a caller of the
+    reference imports: the random starting dictionary must turn into one that explains the signals (events of a hidden
+    dictionary on a noise bed) -- the share of the energy the events explain rises from iteration to iteration."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location(
+        "dictionary_learning_loop", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "examples",
+                                                 "dictionary_learning_loop.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)      # (its mpcore.install() is idempotent: tests/conftest.py installed the overlay already)
+    explained = mod.run(iterations=10, batch=8, log=lambda *_: None)
+    assert explained[0] < 0.5 < explained[-1], explained
+    assert explained[-1] > explained[0] + 0.3 and min(explained[5:]) > explained[0], explained
