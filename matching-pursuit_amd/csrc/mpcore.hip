@@ -1715,10 +1715,10 @@ int fft_iteration(const Geom &g, const Workspace &w, const float *du, int K, int
                                        w.img, w.cont, w.ncont, w.ekeys, g.N, g.A, g.Ns, g.NBLK, g.NAT, g.KC, g.NCH);
             } else {
                 const size_t lds_win = (size_t)(round_up(round_up(g.L, 64) + 128, 64) + 16 * REFINE_ASTR) * sizeof(float);
-                if ((rc = fft_lds_attr(fft_refine_valu_kernel, lds_win))) return rc;
+                if ((rc = fft_lds_attr(fft_refine_chain_kernel, lds_win))) return rc;
                 // (contenders side by side while that still fits the chip: workgroups past a segment's count leave at once)
                 const unsigned ry = (unsigned)std::min<int64_t>(MAXCONT, std::max<int64_t>(1, 2 * (int64_t)num_cus() / (2 * g.B)));
-                hipLaunchKernelGGL(fft_refine_valu_kernel, dim3(2, ry, (unsigned)g.B), dim3(256), lds_win, st, w.res, du,
+                hipLaunchKernelGGL(fft_refine_chain_kernel, dim3(2, ry, (unsigned)g.B), dim3(256), lds_win, st, w.res, du,
                                    w.cont, w.ncont, w.ekeys, g.N, g.A, g.L, g.Ns, g.NAT);
             }
             if (b_tail) {

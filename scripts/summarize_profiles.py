@@ -20,7 +20,7 @@ def newest(pattern):
 
 def short(name):
     for key in ("fft_persistent_kernel", "persist_mark_kernel", "clear_words_kernel", "correlate_persistent_kernel", "correlate_mfma_kernel", "correlate_naive_kernel",
-                "fft_screen_kernel", "fft_correlate_kernel", "fft_refine_valu_kernel",
+                "fft_screen_kernel", "fft_correlate_kernel", "fft_refine_chain_kernel", "fft_refine_valu_kernel",
                 "fft_refine_kernel", "fft_scan_refine_kernel", "fft_select_a_kernel", "fft_select_b_kernel", "fft_select_fused_kernel", "fft_select_quarter_kernel", "fft_window_kernel",
                 "fft_dict_kernel", "fft_twiddle_kernel", "fft_mark_overflow_kernel",
                 "select_subtract_kernel", "unit_norm_kernel", "init_residual_kernel", "copy_residual_kernel",

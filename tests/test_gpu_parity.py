@@ -533,7 +533,7 @@ def test_long_atom_split_transforms_planted_events_and_extreme_amplitudes(oracle
 
 
 def test_four_kernel_refine_with_many_contenders_is_bit_identical(oracle):
-    """The stand-alone refine kernel of the four-kernel form (csrc/mpfft.inc: fft_refine_valu_kernel -- 16 x 16 x 4 matrix-core
+    """The stand-alone refine kernel of the four-kernel form (csrc/mpfft.inc: fft_refine_chain_kernel -- 16 x 16 x 4 matrix-core
     chains, 16 atoms per workgroup, a segment's contenders side by side) on inputs that give it many contenders per
     select: plain noise against long atoms (the screen's bound grows with the atom length), atom counts that leave the
     second workgroup of a cell with no atoms at all / a partly filled tile, chunks of 512 taps with a ragged last one --
