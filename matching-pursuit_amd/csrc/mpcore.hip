@@ -1662,12 +1662,15 @@ int fft_iteration(const Geom &g, const Workspace &w, const float *du, int K, int
             const size_t lds_chain = (size_t)(round_up(g.L, 64) + 128) * sizeof(float);
             MP_FFT_DISPATCH(f.logM, {
                 constexpr int LQ = LG >= 10 ? LG : 10;  // (smaller sizes never get here)
-                const size_t lds_q = lds_chain + ((size_t)f.M + f.M / 64 + 64) * sizeof(cpx);
+                // (behind the chains' window and the twiddles: the transform's buffer, or -- if that takes more -- room for four
+                //  groups of wavefronts to refine four contender quarters side by side)
+                const size_t stage_floats = select_quarter_stage_floats(g.L, f.M);
+                const size_t lds_q = lds_chain + ((size_t)f.M / 64 + 64) * sizeof(cpx) + stage_floats * sizeof(float);
                 if ((rc = fft_lds_attr(fft_select_quarter_kernel<LQ>, lds_q))) return rc;
                 hipLaunchKernelGGL(fft_select_quarter_kernel<LQ>, dim3((unsigned)g.B), dim3(1024), lds_q, st, w.keys,
                                    w.ceps, w.subk, n_cells, w.res, du, w.dirty, w.overflow, out_atom, out_lag, out_gain,
                                    g.N, g.A, g.L, g.Ns, g.NBLK, g.NAT, K, k, rule.du_sub, rule.shift, rule.square, w.tw,
-                                   w.xspec, w.wnorm, f.NW, (const float *)w.dscale, bsum);
+                                   w.xspec, w.wnorm, f.NW, (const float *)w.dscale, bsum, (int)stage_floats);
             })
         } else if (fused) {
             const size_t lds_chain = (size_t)(round_up(g.L, 64) + 128) * sizeof(float);

@@ -131,6 +131,35 @@ __global__ void kE(const float *d, const float *win, float *out, unsigned long l
     if (threadIdx.x < 64 && blockIdx.x == 0) { out[lane] = acc[0]; out[64 + lane] = acc[1]; }
     if (threadIdx.x == 0 && blockIdx.x == 0) { ticks[0] = t1 - t0; ticks[1] = c1 - c0; }
 }
+// F: as D, the atom samples straight from GLOBAL memory (8 rows of a dictionary too large for the L2s, each lane 4 bytes per
+// instruction), a ring of RING requests in flight; the window from LDS.  No staging, no barrier in the loop.
+template <int RING>
+__global__ void kF(const float *d /* rows of L floats, 8 of them used (row i % 8) */, const float *win, float *out, unsigned long long *ticks, int rowstride) {
+    __shared__ float sw[L + 128];
+    const int lane = threadIdx.x & 63;
+    for (int j = threadIdx.x; j < L + 128; j += blockDim.x) sw[j] = win[j];
+    __syncthreads();
+    const unsigned long long t0 = now(), c0 = cyc();
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    const float *ap = d + (size_t)(lane & 7) * rowstride + (lane >> 4);
+    const float *bp = sw + (lane & 15) + (lane >> 4);
+    float ring[RING];
+#pragma unroll
+    for (int u = 0; u < RING; ++u) ring[u] = ap[4 * u];
+    for (int k = 0; k < L; k += 4 * RING) {
+#pragma unroll
+        for (int u = 0; u < RING; ++u) {
+            const float a = ring[u];
+            const int kn = k + 4 * (RING + u);
+            ring[u] = ap[kn < L ? kn : 0];
+            const float b = bp[k + 4 * u];
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc, 0, 0, 0);
+        }
+    }
+    const unsigned long long c1 = cyc(), t1 = now();
+    if (threadIdx.x < 64 && blockIdx.x == 0) out[lane] = acc[0] + acc[1] + acc[2] + acc[3];
+    if (threadIdx.x == 0 && blockIdx.x == 0) { ticks[0] = t1 - t0; ticks[1] = c1 - c0; }
+}
 int main(int argc, char **argv) {
     const int NB = argc > 1 ? atoi(argv[1]) : 1, NT = argc > 2 ? atoi(argv[2]) : 64;
     printf("%d blocks of %d threads, every wavefront the same chain\n", NB, NT);
@@ -146,9 +175,13 @@ int main(int argc, char **argv) {
     float *dd, *dw, *dout; unsigned long long *dt;
     hipMalloc(&dd, d.size() * 4); hipMalloc(&dw, w.size() * 4); hipMalloc(&dout, 512); hipMalloc(&dt, 16);
     hipMemcpy(dd, d.data(), d.size() * 4, hipMemcpyHostToDevice); hipMemcpy(dw, w.data(), w.size() * 4, hipMemcpyHostToDevice);
+    // (kF: a dictionary of 2048 rows x L floats = 32 MB, the 8 rows used 256 rows apart: nothing of it in the L2s at first touch)
+    float *big; hipMalloc(&big, (size_t)2048 * L * 4); hipMemset(big, 0, (size_t)2048 * L * 4);
+    for (int i = 0; i < 8; ++i) hipMemcpy(big + (size_t)i * 256 * L, d.data() + (i & 1) * L, L * 4, hipMemcpyHostToDevice);
     struct V { const char *name; int which; };
     for (V v : {V{"A fmac, LDS-broadcast sample       ", 0}, V{"B two fmac chains interleaved      ", 1}, V{"C readlane + fmac                  ", 2},
-                V{"D mfma 16x16x4                     ", 3}, V{"E pk_fma, two atoms, one b64 sample", 4}}) {
+                V{"D mfma 16x16x4                     ", 3}, V{"E pk_fma, two atoms, one b64 sample", 4},
+                V{"F mfma, atoms from global, ring 16 ", 5}, V{"F mfma, atoms from global, ring 32 ", 6}}) {
         unsigned long long best = ~0ull, t[2], bc = 0;
         for (int rep = 0; rep < 20; ++rep) {
             hipMemset(dout, 0, 512);
@@ -158,6 +191,8 @@ int main(int argc, char **argv) {
                 case 2: hipLaunchKernelGGL(kC, dim3(NB), dim3(NT), 0, 0, dd, dw, dout, dt); break;
                 case 3: hipLaunchKernelGGL(kD, dim3(NB), dim3(NT), 0, 0, dd, dw, dout, dt); break;
                 case 4: hipLaunchKernelGGL(kE, dim3(NB), dim3(NT), 0, 0, dd, dw, dout, dt); break;
+                case 5: hipLaunchKernelGGL(kF<16>, dim3(NB), dim3(NT), 0, 0, big, dw, dout, dt, 256 * L); break;
+                case 6: hipLaunchKernelGGL(kF<32>, dim3(NB), dim3(NT), 0, 0, big, dw, dout, dt, 256 * L); break;
             }
             hipDeviceSynchronize();
             hipMemcpy(t, dt, 16, hipMemcpyDeviceToHost);
@@ -165,12 +200,12 @@ int main(int argc, char **argv) {
         }
         hipMemcpy(o.data(), dout, 512, hipMemcpyDeviceToHost);
         int bad = 0;
-        if (v.which != 3) {
+        if (v.which < 3 || v.which == 4) {
             for (int l = 0; l < 64; ++l) bad += o[l] != ref0[l];
             if (v.which == 1 || v.which == 4) for (int l = 0; l < 64; ++l) bad += o[64 + l] != ref1[l];
         }
         printf("%s: %6.1f us for %d taps = %5.2f ns = %5.1f shader cycles per tap (clock %.2f GHz); lanes differing from the fmaf chain: %d%s\n",
-               v.name, best * 0.01, L, best * 10.0 / L, (double)bc / L, bc / (best * 10.0), bad, v.which == 3 ? " (not compared)" : "");
+               v.name, best * 0.01, L, best * 10.0 / L, (double)bc / L, bc / (best * 10.0), bad, (v.which == 3 || v.which > 4) ? " (not compared)" : "");
     }
     return 0;
 }
