@@ -2105,17 +2105,31 @@ static int encode_impl(const float *signal, int64_t B, int64_t N, const float *d
     //   without           level up to 134 M while the pair spectra fit (<= 8 MB; 2048 x 256 at 268 M: 356 / 397);
     //                    1024 x 1024: 34 M (16) 177 / 178, 67 M 187 / 226; 2048 x 512: 34 M 175 / 164, 67 M 180 / 208
     FftGeom fp;
+    bool short_segments = false;
     bool persist_size = make_fft_geom(g, &fp);
     if (persist_size) {
         const double pairs = (double)((A + 1) / 2);
         const double points = (double)B * pairs * fp.M;
         persist_size = (coherence && !conv_model) ? (B < 48 || points <= (fp.logM == 10 ? 40e6 : 96e6))
                                                   : ((pairs * fp.M * 8.0 <= 8.5e6 && points <= 200e6) || points <= 40e6);
+        // Short segments -- an event dirties half of the segment's lags or more (N <= 4 L: the multiband model's bands are
+        // exactly that) -- leave a select nothing to do ahead of its screen and nothing for the lazy screen to skip, and the
+        // one-launch form keeps only its 256-thread selects and its hand-offs: launch per step with the quarter select (1024
+        // threads, contender quarters side by side) is ahead at 4096-point transforms at every batch size measured (1024 x
+        // 1024 atoms, 4096-sample segments, scripts/small_batch_forms.py, k segment-iterations/s one launch / per step: 1
+        // segment 22 / 31, 8: 115 / 150, 32: 217 / 279, 64: 223 / 307), at 2048-point transforms up to 8 segments (1024 x 512,
+        // 2048 samples: 8: 206 / 233, 16: 359 / 370, 32: 597 / 507), level at 1024 points.
+        if (4 * L >= N && (fp.logM == 12 || (fp.logM == 11 && B <= 8))) {
+            persist_size = false;
+            short_segments = true;
+        }
     }
     const bool persist = path == MP_PATH_FFT && ((flags & MP_FLAG_FFT_PERSISTENT_BIT) || (persist_size && !(flags & forms))) &&
                          !audit_on.load(std::memory_order_relaxed);  // (the audit checks screens launch by launch)
     // a shape the persistent form would take but for its load, with the table: the fused select, which has the lazy screen
-    if (path == MP_PATH_FFT && !persist && coherence && !conv_model && !(flags & forms) && fp.logM >= 10 && fp.logM <= 12 && !fp.split)
+    // (not for short segments: nothing to skip there, and the quarter select is the faster one)
+    if (path == MP_PATH_FFT && !persist && coherence && !conv_model && !(flags & forms) && fp.logM >= 10 && fp.logM <= 12 && !fp.split &&
+        !short_segments)
         flags |= MP_FLAG_FFT_FUSED;
     if (persist) {
         FftGeom f;

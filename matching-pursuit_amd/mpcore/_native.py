@@ -409,12 +409,27 @@ def cached_coherence(dict_unit, build_now=False):
         return None
 
 
-def lazy_pays(batch, n_atoms, n_steps):
+def lazy_pays(batch, n_atoms, n_steps, n_samples=None, atom_samples=None):
     """Is the lazy screen worth asking for (scripts/small_lazy.py, persistent form with / without the table)?  What it saves
     is screen tasks, what it costs is ~1.2 us in every select: it pays where a step has many tile screens to shed -- 512 x 512
     (16 tiles): -1 .. -4 % up to 16 segments, +4 % at 24, +30 % at 64; 1024 x 1024 (32 tiles of 4096-point tasks): +7 % at ONE
     segment, +16 .. +32 % from four; dictionaries of one or two tiles (64 x 300, 16 x 256): -5 % at any batch."""
     tiles = (int(n_atoms) + 31) // 32
+    if n_samples is not None and atom_samples is not None:
+        # (the table is validated against the dictionary call after call -- a pass over both copies and a handful of host
+        #  operations, 0.13 ms at 1024 x 2048 -- so it is only asked for where the library would look at it:)
+        L, N = int(atom_samples), int(n_samples)
+        log_m = max(8, (3 * L + 190 - 1).bit_length())        # csrc/mpfft.inc: make_fft_geom -- M = 2^log_m >= 3 L + 190
+        if log_m >= 13 and ((N + 63) // 64) * tiles < 65536:
+            # transforms of 8192 points and more: no persistent form, and the launch-per-step lazy screen lives in the fused
+            # select, which only segments of 65536 cells and more take
+            return False
+        if 4 * L >= N:
+            # short segments (an event dirties half of the lags or more): at 4096-point transforms, and at 2048 points up to
+            # 8 segments, they run launch per step on the quarter select (csrc/mpcore.hip: encode_impl, short_segments);
+            # in the persistent form the table loses too (scripts/small_batch_forms.py, 1024 x 512 atoms, 2048-sample
+            # segments, planted events, with / without: 8 segments 206 / 214 k, 32: 552 / 597 k)
+            return False
     return int(n_steps) >= 8 and tiles >= 4 and (tiles >= 32 or int(batch) * tiles >= 384)
 
 
@@ -456,7 +471,7 @@ def encode(signal, dict_unit, n_steps, path=MP_PATH_INCREMENTAL, flags=0, want_r
                 residual[sl] = r
         _tls.lazy = any_lazy
         return atom, lag, gain, residual
-    if coherence is None and path == MP_PATH_FFT and not conv_model and lazy_pays(B, A, K) and \
+    if coherence is None and path == MP_PATH_FFT and not conv_model and lazy_pays(B, A, K, N, L) and \
             not (int(flags) & ~MP_FLAG_FFT_PERSISTENT):
         # a batch large enough for the table to pay for itself within this one call gets it at once, new dictionary or not:
         # the table is A * A / 2 transforms, the launch it trims B (K - 1) A / 2, of which a third go (512 atoms, 64 steps:
@@ -554,7 +569,7 @@ class EncodePlan:
         else:
             groups = max(2, min(4, int(sub_batches)))
         if lazy is None:
-            lazy = (groups == 0 and self.path == MP_PATH_FFT and lazy_pays(batch, A, n_steps) and
+            lazy = (groups == 0 and self.path == MP_PATH_FFT and lazy_pays(batch, A, n_steps, n_samples, L) and
                     not (int(flags) & ~MP_FLAG_FFT_PERSISTENT))
         self.lazy = bool(lazy) and self.path == MP_PATH_FFT and lib().mp_coherence_workspace_bytes(A, L) > 0
         self._dict_copy = self._table = None

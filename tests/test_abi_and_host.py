@@ -375,3 +375,8 @@ def test_when_the_mirror_asks_for_the_lazy_screen():
     assert nat.lazy_pays(1, 1024, 32) and nat.lazy_pays(128, 4096, 256)
     assert not nat.lazy_pays(24, 64, 16) and not nat.lazy_pays(1000, 16, 8) and not nat.lazy_pays(1000, 64, 16)   # one or two tiles: never
     assert not nat.lazy_pays(64, 512, 4)
+    # ... and only where the library would look at the table: not at 8192-point transforms below 65536 cells per segment,
+    # not for short segments, which run launch per step on the quarter select (csrc/mpcore.hip: short_segments)
+    assert nat.lazy_pays(64, 512, 64, 32768, 512) and nat.lazy_pays(128, 4096, 256, 131072, 2048)
+    assert not nat.lazy_pays(8, 1024, 32, 8192, 2048) and not nat.lazy_pays(8, 1024, 32, 4096, 1024)
+    assert not nat.lazy_pays(8, 1024, 32, 2048, 512) and not nat.lazy_pays(16, 1024, 32, 2048, 512) and nat.lazy_pays(8, 1024, 32, 32768, 1024)
