@@ -840,6 +840,19 @@ def test_which_form_the_default_schedule_takes():
         assert nat.last_schedule() == want, (n, co is not False, nat.last_schedule())
         assert (nat.lazy_stats()["decided"] > 0) == (co is not False and want != -1)
         assert all(torch.equal(p, q[:n]) for p, q in zip(out, ref4)), (n, co is not False)
+    # ... nor for SHORT segments (an event dirties half of the lags or more: N <= 4 L, the multiband model's bands): launch per
+    # step on the quarter select at 4096-point transforms, and at 2048 points up to 8 segments (scripts/small_batch_forms.py)
+    for A5, L5, N5, cases in ((96, 1024, 4096, ((4, 1), (20, 1))), (96, 512, 2048, ((8, 1), (9, -1))), (96, 1024, 4100, ((4, -1),)),
+                              (96, 256, 1024, ((4, -1),))):
+        d5 = synth.make_dictionary(A5, L5, seed=57)
+        du5 = nat.unit_norm(torch.from_numpy(d5).to(DEV))
+        x5 = torch.from_numpy(synth.make_segments(20, N5, d5, n_events=6, seed=58)).to(DEV)
+        ref5 = nat.encode(x5, du5, 4, path=nat.MP_PATH_FFT, flags=nat.MP_FLAG_FFT_PERSISTENT, coherence=False)
+        assert nat.last_schedule() == -1
+        for n, want in cases:
+            out = nat.encode(x5[:n], du5, 4, path=nat.MP_PATH_FFT, coherence=False)
+            assert nat.last_schedule() == want, (L5, N5, n, nat.last_schedule())
+            assert all(torch.equal(p, q[:n]) for p, q in zip(out, ref5)), (L5, N5, n)
 
 
 def test_coherence_table_bounds_the_exact_one():
