@@ -68,17 +68,25 @@ torch.cuda.empty_cache()
 # configs[3]
 A, L, N, B, K = 4096, 2048, 131072, 128, 256
 d = synth.make_dictionary(A, L, seed=4000)
-xh = synth.make_segments(B, N, d, n_events=256, seed=4001)
+xh = synth.make_segments(B, N, d, n_events=3 * K, seed=4001)   # E = 3 K planted events per segment
 x = torch.from_numpy(xh).to(DEV)
 du = nat.unit_norm(torch.from_numpy(d).to(DEV))
 nat.encode(x[:4], du, 2, path=nat.MP_PATH_FFT); torch.cuda.synchronize()
+runs = []
+for _ in range(3):   # (the first call also builds the dictionary's coherence table, 40 ms)
+    t0 = time.perf_counter()
+    atom, lag, gain, res = nat.encode(x, du, K, path=nat.MP_PATH_FFT)
+    torch.cuda.synchronize()
+    runs.append(time.perf_counter() - t0)
 t0 = time.perf_counter()
-atom, lag, gain, res = nat.encode(x, du, K, path=nat.MP_PATH_FFT)
+nat.encode(x, du, K, path=nat.MP_PATH_FFT, coherence=False)
 torch.cuda.synchronize()
-dt = time.perf_counter() - t0
+dt_plain = time.perf_counter() - t0
+dt = min(runs)
 rec = torch.zeros_like(x)
 nat.scatter(atom, torch.arange(B, device=DEV)[:, None].expand(B, K), lag, gain, du, rec)
-out["configs[3]"] = {"shape": "A4096 L2048 N131072 B128 K256", "encode_s": round(dt, 3),
+out["configs[3]"] = {"shape": "A4096 L2048 N131072 B128 K256, 768 planted events per segment", "encode_s": round(dt, 3),
+                     "encode_s_first_call": round(runs[0], 3), "encode_s_without_the_coherence_table": round(dt_plain, 3),
                      "segment_iterations_per_s": round(B * K / dt),
                      "round_trip_max_abs_error": float((rec + res - x).abs().max()),
                      "residual_db": round(float(20 * torch.log10(res.norm() / x.norm())), 2),
