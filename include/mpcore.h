@@ -135,7 +135,9 @@ int mp_profile_enable(int every);
                                      (one small kernel per step builds it); 0 = every workgroup of the full grid looks its mask up and
                                      returns if it is set.  Same results either way                                              */
 #define MP_TUNE_CLEAR_MEMSET 15    /* debug: 1 = the encode's clears are hipMemsetAsync calls instead of one kernel launch (what a
-                                     stream capture makes of memset nodes: scripts/graph_memset_repro.py); 0 (default) */
+                                     stream capture makes of memset nodes: scripts/graph_memset_repro.py); 0 (default).
+                                     Replayed from a hipGraph those memset nodes leave WRONG events on this runtime, so 1 is refused
+                                     unless the process has MP_ALLOW_WRONG_RESULTS=1 in its environment, like MP_TUNE_LAZY_FORCE   */
 int mp_tune(int key, double value);
 int mp_profile_read(double *ms, int64_t *count);
 

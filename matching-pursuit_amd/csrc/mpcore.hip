@@ -1685,17 +1685,19 @@ int fft_iteration(const Geom &g, const Workspace &w, const float *du, int K, int
                                    lazy_form && k >= 1 ? lz.mu : (const float *)nullptr, tau, lz.margin, lz.reuse,
                                    (const float *)w.lfloor, lazy_form && k >= 1 ? w.skip : (unsigned *)nullptr, lz.force);
             })
-            if (lazy_form && k >= 1 && k + 1 < K && w.work != nullptr && g.B <= 65535 && lazy_compact.load(std::memory_order_relaxed) != 0)
+            if (lazy_form && k >= 1 && k + 1 < K && w.work != nullptr && g.B <= 65535 && lazy_compact.load(std::memory_order_relaxed) != 0) {
                 hipLaunchKernelGGL(lazy_compact_kernel, dim3(1), dim3(1024), 0, st, (const unsigned *)w.skip, (int)g.B, g.NAT, w.work);
+                HIP_TRY(hipGetLastError());
+            }
             if (lazy_form && k == 0 && K > 2) {
                 // the lazy screen's floor: where this run's maxima are expected to end -- the (K + K/16 + 1)-th largest peak
                 // among the CELLS after step 0's select (mplazy.inc: lazy_floor_cells_kernel; peaks dominate their own
                 // tile's cells `radius` blocks either side)
-                const int tuned = persist_radius.load(std::memory_order_relaxed);
-                const int radius = tuned > 0 ? tuned : tuned < 0 ? 0 : (int)(1 + std::max<int64_t>(0, (g.L - 512 + 255) / 256));
+                const int radius = lazy_radius_for(g.L, 0 /* by atom length: the floor counts cells, not blocks */, K);
                 hipLaunchKernelGGL(lazy_floor_cells_kernel, dim3((unsigned)g.B), dim3(1024), 0, st, (const u64 *)w.keys,
                                    (const float *)w.ceps, (const unsigned *)w.bsum, g.NBLK, g.NAT, lazy_rank_for(K), radius,
                                    w.lfloor);
+                HIP_TRY(hipGetLastError());
             }
         } else {
             // select-A merged into the refinement launch when select-B is the kernel that clears the slots
@@ -1978,7 +1980,14 @@ int mp_tune(int key, double value) {
         lazy_force.store((float)value);
         return MP_OK;
     }
-    if (key == MP_TUNE_CLEAR_MEMSET && (value == 0 || value == 1)) { clear_with_memset.store((int)value); return MP_OK; }
+    if (key == MP_TUNE_CLEAR_MEMSET && (value == 0 || value == 1)) {
+        // (hipMemsetAsync clears captured into a hipGraph replay a stale fill pattern on this runtime -- wrong events under
+        //  EncodePlan, profiles/r03_graph_memset_*.txt -- so the switch is a repro instrument behind the same environment gate)
+        const char *ok = getenv("MP_ALLOW_WRONG_RESULTS");
+        if (value > 0 && !(ok && ok[0] == '1')) return fail(MP_ERR_ARG, "mp_tune(MP_TUNE_CLEAR_MEMSET): set MP_ALLOW_WRONG_RESULTS=1 in the environment%s");
+        clear_with_memset.store((int)value);
+        return MP_OK;
+    }
     if (key == MP_TUNE_LAZY_COMPACT && (value == 0 || value == 1)) { lazy_compact.store((int)value); return MP_OK; }
     if (key == MP_TUNE_PERSIST_FINE && value >= 0 && value <= 2) { persist_fine.store((int)value); return MP_OK; }
     return fail(MP_ERR_ARG, "mp_tune: unknown key or bad value%s");

@@ -268,13 +268,14 @@ def encode_checked(signal, dict_unit, n_steps, flags=0, want_residual=True):
     return atom, lag, gain, residual
 
 
-def coherence_table(dict_unit, chunk=128, exact=False):
+def coherence_table(dict_unit, chunk=128, exact=False, slack=True):
     """The dictionary's coherence table for the lazy screen (mp_encode_lazy_f32): [A, NAT] f32 on the device,
     entry (a, t) >= max over the 32 atoms b of tile t and all shifts s of |sum_j d_a[j] d_b[j + s]|.
     Default: mp_coherence_f32 -- one full-pass FFT screen of the atoms against the dictionary, |.| maxima plus the
     screen's bound (~0.3 ms at the headline dictionary); where that does not exist (transform sizes the lazy screen
     does not cover) or with exact=True: exact correlations of every atom, placed in a zero row, with the whole dictionary
-    (mp_feature_map_f32), plus the fp32 chain's worst-case rounding u L (~5 ms)."""
+    (mp_feature_map_f32), plus the fp32 chain's worst-case rounding u L (~5 ms; slack=False leaves that term out: the
+    computed correlations themselves, for tests)."""
     dict_unit = _f32(dict_unit)
     _require_cuda(dict_unit)
     A, L = dict_unit.shape
@@ -303,6 +304,8 @@ def coherence_table(dict_unit, chunk=128, exact=False):
         if pad:
             m = torch.nn.functional.pad(m, (0, pad))
         out[a0:a0 + n] = m.view(n, nat_tiles, 32).amax(dim=-1)
+    if not slack:
+        return out
     return out + float(L) * 5.9604645e-8 * float(dict_unit.norm(dim=-1).max()) ** 2
 
 

@@ -13,6 +13,8 @@ import ctypes
 import os
 import sys
 
+os.environ["MP_ALLOW_WRONG_RESULTS"] = "1"   # mp_tune(MP_TUNE_CLEAR_MEMSET, 1) is refused without it: this script IS the repro
+
 import numpy as np
 import torch
 

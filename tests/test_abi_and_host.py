@@ -356,6 +356,54 @@ def test_event_lists_are_lazy_and_equal_to_the_eager_structures():
     assert len(empty.instances()) == 0 and len(empty.flat()) == 0 and list(empty.flat()) == []
 
 
+def test_event_lists_and_c_level_consumers():
+    """Consumers of an UNMATERIALISED EventList that are implemented in C, pinned (INTEGRATION.md "Event lists").  On this
+    interpreter (CPython 3.10) the exact-storage fast paths are taken for EXACT lists only (PyList_CheckExact), so a list
+    subclass goes through __iter__ / __len__ / __getitem__ and everything below sees the tuples: slice assignment from
+    the list, extend, tuple(), deque(), numpy.array(dtype=object), heapq.nsmallest, the json encoder, copy / deepcopy.
+    The one consumer found that reads the storage of a list SUBCLASS directly is in-place heapq.heapify (PyList_Check +
+    ob_item): on an unmaterialised list it orders nothing.  Below EAGER_EVENTS events sparse_code hands out materialised
+    lists, for which heapify too behaves as for a plain list."""
+    import collections
+    import copy
+    import heapq
+    import json
+    import mpcore.matchingpursuit as mpm
+    rng = np.random.default_rng(4)
+    B, K, A, L = 3, 4, 5, 4
+    atom = torch.from_numpy(rng.integers(0, A, size=(B, K)))
+    lag = torch.from_numpy(rng.integers(0, 50, size=(B, K)))
+    gain = torch.from_numpy(rng.standard_normal((B, K)).astype(np.float32))
+    du = torch.from_numpy(rng.standard_normal((A, L)).astype(np.float32))
+    store = mpm._EventStore(atom, lag, gain, du, torch.device("cpu"), A)
+    n = B * K
+    target = [None]
+    target[0:1] = store.flat()
+    assert len(target) == n
+    grown = []
+    grown.extend(store.flat())
+    assert len(grown) == n and len(tuple(store.flat())) == n and len(collections.deque(store.flat())) == n
+    assert np.array(store.flat(), dtype=object).shape[0] == n
+    assert len(heapq.nsmallest(2, store.flat(), key=lambda e: e[1])) == 2
+    assert len(json.loads(json.dumps(store.flat(), default=lambda o: 0))) == n
+    assert len(copy.copy(store.flat())) == n and len(copy.deepcopy(store.flat())) == n
+    assert len(list(store.flat())) == n and len([] + store.flat()) == n and len(sum([store.flat()], [])) == n
+    # the known-unsafe one: heapify works on the C storage, which an unmaterialised list has not filled yet
+    by_batch = lambda ev: [(e[1], e[0], int(e[2])) for e in ev]   # noqa: E731  (tensors do not order; keys do)
+    lazy = store.flat()
+    heapq.heapify(lazy)
+    assert lazy._store is not None and list.__len__(lazy) == 0        # nothing was ordered, nothing was built
+    # materialised (what sparse_code returns for small encodes): a plain list to everybody
+    keyed = mpm.EventList(by_batch(store.flat(eager=True)))
+    heapq.heapify(keyed)
+    assert list.__len__(keyed) == n and keyed[0] == min(by_batch(store.flat()))
+    eager = store.flat(eager=True)
+    assert eager._store is None and list.__len__(eager) == n and eager.packed is not None
+    inst = store.instances(eager=True)
+    assert all(v._store is None and list.__len__(v) == len(v) for v in inst.values())
+    assert mpm.EAGER_EVENTS >= 256
+
+
 def test_the_timing_only_knob_is_refused_without_its_environment_variable(monkeypatch):
     """mp_tune(MP_TUNE_LAZY_FORCE) draws the lazy screen's tile masks at random -- an instrument for timing the screen
     against the share and pattern of skipped workgroups; the events are wrong while it is set.  No product
@@ -367,6 +415,15 @@ def test_the_timing_only_knob_is_refused_without_its_environment_variable(monkey
     monkeypatch.setenv("MP_ALLOW_WRONG_RESULTS", "1")
     nat.tune(nat.MP_TUNE_LAZY_FORCE, 1.5)
     nat.tune(nat.MP_TUNE_LAZY_FORCE, 0)
+    # ... and the same gate on MP_TUNE_CLEAR_MEMSET: hipMemsetAsync clears replayed from a hipGraph leave wrong events on
+    # this runtime, so only the repro script (which sets the variable) may switch them on
+    monkeypatch.delenv("MP_ALLOW_WRONG_RESULTS", raising=False)
+    with pytest.raises(nat.NativeError):
+        nat.tune(nat.MP_TUNE_CLEAR_MEMSET, 1)
+    nat.tune(nat.MP_TUNE_CLEAR_MEMSET, 0)
+    monkeypatch.setenv("MP_ALLOW_WRONG_RESULTS", "1")
+    nat.tune(nat.MP_TUNE_CLEAR_MEMSET, 1)
+    nat.tune(nat.MP_TUNE_CLEAR_MEMSET, 0)
 
 
 def test_when_the_mirror_asks_for_the_lazy_screen():
