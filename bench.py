@@ -87,6 +87,72 @@ def valu_per_thread_transform(kind, log_m):
     return _valu_cache[key]
 
 
+def min_valu_per_thread_transform(log_m):
+    """The ALGORITHM's packed-fp32 instruction count per thread and transform -- what `roofline.frac` is priced by, instead of
+    the built kernel's own count (valu_per_thread_transform, which a fatter kernel would raise).  One thread carries 16 of
+    the M points of one atom PAIR's transform (two real correlations per complex transform); a complex add, a complex
+    multiply-by-i-and-add is ONE v_pk_add_f32, a complex multiply is TWO (v_pk_mul_f32 + v_pk_fma_f32).  Counted for the
+    Stockham factorisation the screen runs (csrc/mpfft.inc::ScreenCfg: M = R0 x 16 x .. x 16 [x RS]), with EVERY twiddle
+    factor a ready operand (loads are not VALU; the kernels compute some factors as powers instead -- that is overhead):
+      spectrum product X . P          16 complex multiplies                                             = 32
+      first pass, radix 8             2 x idft8  = 2 x (2 idft4 x 8 adds + 2 constant multiplies x 2 + 8 adds)   = 56
+      first pass, radix 16            idft16 = 4 idft4 x 8 + 8 constant multiplies x 2 + 4 idft4 x 8              = 80
+      every later radix-16 pass       15 twiddle multiplies x 2 + idft16                                  = 110
+      last pass, radix 4 / radix 2    4 x (3 twiddles x 2 + idft4 8) = 56  /  8 x (1 twiddle x 2 + 2 adds) = 32
+      running maximum over the pair   16 v_max3_f32 (both atoms' values of a lag in one instruction)              = 16
+    -> (count, breakdown)."""
+    rs = 16 if log_m % 4 == 0 else 1 << (log_m % 4)
+    small_last = rs < 8
+    r0 = 16 if small_last else rs
+    n16 = (log_m // 4 - 1) if (small_last or log_m % 4 == 0) else log_m // 4
+    parts = {"spectrum_product": 32, "first_pass_radix_%d" % r0: 56 if r0 == 8 else 80,
+             "radix_16_passes": [110] * n16, "last_pass_radix_%d" % rs: ({4: 56, 2: 32}[rs] if small_last else 0),
+             "running_maximum": 16}
+    total = 32 + (56 if r0 == 8 else 80) + 110 * n16 + parts["last_pass_radix_%d" % rs] + 16
+    return total, parts
+
+
+def flops_per_transform(log_m):
+    """Textbook flop price of one M-point complex transform with its spectrum product: 5 M log2 M + 6 M."""
+    m = 1 << log_m
+    return 5.0 * m * log_m + 6.0 * m
+
+
+def pmc_valu_fraction(kind, which):
+    """VALU-busy x measured clock / 2.4 GHz of the dominant kernel from the newest committed counter pass
+    (profiles/rNN_<kind>_summary.json: sq_counters_dominant_kernel[which]) -> dict or None."""
+    import glob
+    for f in sorted(glob.glob(os.path.join(REPO, "profiles", f"r*_{kind}_summary.json")), reverse=True):
+        try:
+            c = json.load(open(f))["sq_counters_dominant_kernel"][which]
+            return {"value": round(c["valu_busy_frac_of_simd_cycles"] * c["clock_GHz"] / (PEAK_CLOCK_HZ / 1e9), 4),
+                    "valu_busy_frac_of_simd_cycles": c["valu_busy_frac_of_simd_cycles"], "clock_GHz": c["clock_GHz"],
+                    "avg_us_under_counters": c["avg_us"], "from": "profiles/" + os.path.basename(f)}
+        except (OSError, ValueError, KeyError):
+            continue
+    return None
+
+
+def algorithmic_fractions(transforms, log_m, seconds, valu_code):
+    """The three prices of the same launch time: the algorithm's minimal packed-fp32 instructions (-> frac), the built
+    kernel's own instruction count (-> frac_issue), textbook flops (-> frac_flops).  `transforms` pair transforms of
+    2^log_m points ran in `seconds`."""
+    waves = (1 << log_m) // 16 // 64
+    vmin, parts = min_valu_per_thread_transform(log_m)
+    g_min = transforms * waves * vmin / seconds / 1e9
+    g_code = transforms * waves * valu_code / seconds / 1e9
+    tfl = transforms * flops_per_transform(log_m) / seconds / 1e12
+    return {
+        "achieved": round(g_min, 1), "frac": round(g_min / PEAK_VALU_GINSTR, 4),
+        "priced_by": "minimal packed-fp32 instructions of the transform the screen runs (min_valu: derivation in "
+                     "bench.py::min_valu_per_thread_transform), NOT the kernel's own count",
+        "min_valu": {"per_thread_transform": vmin, "breakdown": parts, "waves_per_transform": waves},
+        "frac_issue": round(g_code / PEAK_VALU_GINSTR, 4), "achieved_issue": round(g_code, 1),
+        "frac_flops": round(tfl / PEAK_MFMA_F32_TFLOPS, 4), "tflops": round(tfl, 2),
+        "flops_per_transform": flops_per_transform(log_m), "peak_tflops_f32_vector": PEAK_MFMA_F32_TFLOPS,
+    }
+
+
 PATHS = {"fft": nat.MP_PATH_FFT, "incremental": nat.MP_PATH_INCREMENTAL, "direct": nat.MP_PATH_DIRECT}
 
 
@@ -236,15 +302,15 @@ def roofline_fft(prof, sh, steps, lazy=None):
     transforms = all_transforms - skipped_transforms
     waves = sh.M // 16 // 64
     wave_instr = transforms * waves * valu
-    achieved = wave_instr / sec / 1e9
     traffic = pmc_traffic("fft_screen" if sh is HEAD else "c3_fft_screen")
     out = {
-        "bound": "valu", "achieved": round(achieved, 1), "peak": round(PEAK_VALU_GINSTR, 1),
-        "unit": "G wave64-instructions/s (packed fp32 issue)",
-        "frac": round(achieved / PEAK_VALU_GINSTR, 4), "traffic": traffic,
+        "bound": "valu", "peak": round(PEAK_VALU_GINSTR, 1),
+        "unit": "G wave64 packed-fp32 instructions/s", "traffic": traffic,
         "kernel": f"fft_screen_kernel<{sh.log_m}> (radix-16 Stockham, packed fp32)",
         "valu_per_thread_transform": valu, "valu_count_from": valu_src,
     }
+    out.update(algorithmic_fractions(transforms, sh.log_m, sec, valu))
+    out["frac_from_pmc"] = pmc_valu_fraction("fft" if sh is HEAD else "c4", "incremental")
     out.update(per_kind)
     avg_s = sec / per_kind["launches"]
     if traffic is not None:
@@ -305,13 +371,13 @@ def roofline_persistent(prof, sh, steps):
     valu0, _ = valu_per_thread_transform("screen", sh.log_m)     # (step 0's full pass is fft_screen_kernel)
     wave_instr = transforms * waves * valu
     avg_s = ms_p / n_p * 1e-3
-    achieved = wave_instr / avg_s / 1e9
     traffic = pmc_traffic("fft_persistent") if sh is HEAD else None   # (the PMC passes profiled the headline batch)
     t0 = sh.B * (sh.A // 2) * sh.nw_full
-    out = {
-        "bound": "valu", "achieved": round(achieved, 1), "peak": round(PEAK_VALU_GINSTR, 1),
-        "unit": "G wave64-instructions/s (packed fp32 issue)",
-        "frac": round(achieved / PEAK_VALU_GINSTR, 4), "traffic": traffic,
+    out = {"bound": "valu", "peak": round(PEAK_VALU_GINSTR, 1), "unit": "G wave64 packed-fp32 instructions/s"}
+    out.update(algorithmic_fractions(transforms, sh.log_m, avg_s, valu))
+    out["frac_from_pmc"] = pmc_valu_fraction("persist", "persistent_launch") if sh is HEAD else None
+    out.update({
+        "traffic": traffic,
         "kernel": "fft_persistent_kernel<11,2> (queue of radix-16 Stockham screen tasks + select workers, three "
                   "workgroups per CU, one launch for steps 1 .. K-1)",
         "launches": steps, "avg_launch_ms": round(avg_s * 1e3, 5),
@@ -323,7 +389,7 @@ def roofline_persistent(prof, sh, steps):
                                         / PEAK_VALU_GINSTR, 4) if n_full else None,
         "valu_per_thread_transform": valu, "valu_count_from": valu_src,
         "other_kernels_avg_ms_per_encode": round(prof["select"][0] / max(n_p, 1), 5),
-    }
+    })
     if traffic is not None:
         out["hbm_gbs_measured"] = round(traffic / avg_s / 1e9, 1)
         out["frac_hbm"] = round(traffic / avg_s / 1e9 / PEAK_HBM_GBS, 4)
@@ -587,6 +653,102 @@ def configs3_variant(dev):
     }
     del x, rec, out, plain
     torch.cuda.empty_cache()
+    return res
+
+
+def next_rows_variants(dev, steps):
+    """SURVEY.md 8(f)'s rows on the driver line (they lived in scripts/ only): the multiband model on
+    the band table of experiments/archive/e_2023_3_8/experiment.py:351-359, the streaming encode of a 2^20-sample
+    recording at a 50 % hop (iterativedecomposition.py:275-319's shape), one training step of the mp.py model at BASELINE
+    configs[4]'s shape (512 x 512, 8 x 32768 samples, K = 32, STFT(2048, 256) iterative loss, Adam).  One line each."""
+    import mpcore  # noqa: F401
+    from mpcore import multibanddict as mb
+    from mpcore import streaming
+    from mpcore.model import MatchingPursuit, train_step
+    v = {}
+    reps = max(2, min(steps, 5))
+    # ---- multiband: seven bands 512 .. 32768 samples, 1024 atoms of band / 4 samples each, 32 steps per band, B = 8 ----
+    Bm, n_atoms, msteps, n = 8, 1024, 32, 2 ** 15
+    sizes = [512, 1024, 2048, 4096, 8192, 16384, 32768]
+    specs = [mb.BandSpec(sz, n_atoms, sz // 4, device=dev, signal_samples=n, is_lowest_band=(sz == 512)) for sz in sizes]
+    model = mb.MultibandDictionaryLearning(specs, n_samples=n)
+    rng = np.random.default_rng(5)
+    xm = torch.from_numpy(rng.standard_normal((Bm, 1, n)).astype(np.float32)).to(dev)
+    t = torch.arange(n, device=dev)[None, None, :]
+    for f0 in (60., 250., 900., 2500., 6000.):   # (structure in every band: decaying sinusoids at random onsets)
+        on = int(rng.integers(0, n // 2))
+        xm = xm * 0.97 + 3.0 * torch.sin(2 * np.pi * f0 / 22050. * t) * torch.exp(-(t - on).clamp(min=0) / 3000.) * (t >= on)
+    model.encode(xm, msteps)
+    sec_e, _ = _rate(lambda: model.encode(xm, msteps), reps)
+    sec_r, rec = _rate(lambda: model.recon(xm, msteps), reps)
+    sec_l, _ = _rate(lambda: model.learn(xm, msteps), 2)
+    v["multiband_e_2023_3_8"] = {
+        "value": round(7 * Bm * msteps / sec_e, 1), "unit": "band-segment-iterations/s", "encode_ms": round(sec_e * 1e3, 2),
+        "recon_ms": round(sec_r * 1e3, 2), "learn_ms": round(sec_l * 1e3, 2), "batch": Bm, "steps_per_band": msteps,
+        "bands": [[sz, n_atoms, sz // 4] for sz in sizes],
+        "residual_energy_share": round(float(((xm - rec[0]) ** 2).sum() / (xm ** 2).sum()), 4),
+        "note": "mpcore.multibanddict.MultibandDictionaryLearning.encode / recon / learn (dictionary_learning_step per band) "
+                "on noise + decaying sinusoids; atoms of 8192 samples run the split 2^14-point transforms"}
+    del model, specs, xm, rec
+    # ---- streaming: one 2^20-sample recording per row, windows of 32768 at hop 16384, even / odd batches ----
+    Bs, T, window, hop, Ks = 2, 2 ** 20, 32768, 16384, 64
+    d = synth.make_dictionary(A, L, seed=1000)
+    # (the recording: 32 headline-like segments end to end -- 3 K planted events, a note bed and noise per 32768 samples)
+    audio = torch.from_numpy(synth.make_segments(Bs * (T // window), window, d, n_events=3 * Ks, seed=3003).reshape(Bs, T)).to(dev)
+    dd = torch.from_numpy(d).to(dev)
+    W = streaming.n_windows(T, window, hop)
+    sec_s, code = _rate(lambda: streaming.encode_streaming(audio, dd, window, hop, Ks, order="even_odd"), reps)
+    # the same number of window-encodes as two plain batches (no residual hand-over, no stacking / scatter of windows)
+    seg = torch.stack([audio[:, w * hop:w * hop + window] for w in range(0, W - 1, 2)], dim=1).reshape(-1, window).contiguous()
+    du_s = nat.unit_norm(dd)
+    sec_plain, _ = _rate(lambda: (nat.encode_checked(seg, du_s, Ks), nat.encode_checked(seg, du_s, Ks)), reps)
+    rt = float((streaming.decode_streaming(code) + code.residual - audio).abs().max())
+    v["streaming_even_odd"] = {
+        "value": round(Bs * W * Ks / sec_s, 1), "unit": "segment-iterations/s", "ms_per_recording_batch": round(sec_s * 1e3, 2),
+        "recordings": Bs, "samples": T, "window": window, "hop": hop, "windows": W, "iterations_per_window": Ks,
+        "two_plain_batches_of_the_same_size_ms": round(sec_plain * 1e3, 2),
+        "share_lost_to_window_hand_over": round(max(0.0, 1.0 - sec_plain / sec_s), 4),
+        "round_trip_max_err": rt,
+        "note": "mpcore.streaming.encode_streaming(order='even_odd'): windows of equal parity as one batch each, the second on "
+                "what the first left; hand-over = stacking the windows, writing residuals back, the odd batch waiting for the even one"}
+    del audio, seg, code
+    # ---- configs[4]: one training step of the mp.py model at its own shape ----
+    A5, L5, N5, B5, K5 = 512, 512, 32768, 8, 32
+    torch.manual_seed(0)
+    m5 = MatchingPursuit(A5, L5, N5, K5).to(dev)
+    d5 = synth.make_dictionary(A5, L5, seed=5000)
+    with torch.no_grad():
+        m5.atoms.copy_(torch.from_numpy(d5)[None].to(dev) * 0.05)
+    opt = torch.optim.Adam(m5.parameters(), lr=1e-3)
+    x5 = torch.from_numpy(synth.make_segments(B5, N5, d5, n_events=3 * K5, seed=5001)).to(dev)[:, None, :]
+    for _ in range(2):
+        train_step(m5, opt, x5, ("stft", 2048, 256))
+    sec_t, loss = _rate(lambda: train_step(m5, opt, x5, ("stft", 2048, 256)), max(reps, 4))
+    atoms = m5.atoms[0].detach()
+    sec_f, _ = _rate(lambda: nat.encode(x5[:, 0], atoms, K5, path=nat.default_path(L5), conv_model=True), max(reps, 4))
+    v["config5_train_step"] = {
+        "value": round(B5 * K5 / sec_t, 1), "unit": "segment-iterations/s", "ms_per_step": round(sec_t * 1e3, 3),
+        "analysis_loop_only_ms": round(sec_f * 1e3, 3), "loss": round(float(loss), 4),
+        "shape": {"atoms": A5, "atom_samples": L5, "segments": B5, "samples": N5, "iterations": K5, "stft": [2048, 256]},
+        "note": "mpcore.model.train_step: mp_encode_conv_f32 (mp.py:58-65), event form of iterative_loss under "
+                "stft(x, 2048, 256, pad=True) (mp.py:68-70, 102-104), mp_conv_model_backward_f32, Adam; one rank: the "
+                "gradient all-reduce is the identity (world size 1)"}
+    del m5, x5
+    torch.cuda.empty_cache()
+    return v
+
+
+def lcn_variant(x, du, steps):
+    """The local-contrast-norm schedule (sparse_code(local_contrast_norm=True), modules/matchingpursuit.py:284-294; used
+    with 512 steps by experiments/archive/e_2023_7_20/experiment.py:31-41) at the headline shape: 64 x 32768, K = 64."""
+    B, K = HEAD.B, HEAD.K
+    sec, out = _rate(lambda: nat.encode_lcn(x, du, K), max(1, min(steps, 3)))
+    plain = nat.encode(x, du, K, path=nat.MP_PATH_FFT)
+    torch.cuda.synchronize()
+    res = {"value": round(B * K / sec, 1), "unit": "segment-iterations/s", "ms_per_step": round(sec * 1e3, 3),
+           "share_of_picks_that_differ_from_the_plain_rule": round(float(((out[0] != plain[0]) | (out[1] != plain[1])).float().mean()), 4),
+           "residual_db_mean": round(float((20 * torch.log10(out[3].norm(dim=-1) / x.norm(dim=-1))).mean()), 3)}
+    res.update(nat.lcn_stats() if hasattr(nat, "lcn_stats") else {})
     return res
 
 

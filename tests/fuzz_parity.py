@@ -36,7 +36,8 @@ for case in range(n_cases):
         A = int(rng.choice([1, 2, 33])); L = int(rng.choice([1, 2, 3])); N = int(rng.integers(1, 70)); B = int(rng.choice([1, 3, 40]))
     if case % 10 == 2:   # many more steps than the segment has structure: the tail of the run is rounding noise
         A = int(rng.integers(2, 20)); L = int(rng.choice([8, 32])); N = int(rng.integers(100, 600)); B = 3; K = 40
-    if case % 10 == 3:   # more than 16384 cells per segment: the block-summary select (short atoms) / the four-kernel form
+    if case % 10 == 3:   # more than 16384 cells per segment: up to 65536 the persistent form with the fused whole-cell step 0
+                         # (1024- to 4096-point transforms, the default since round 3), the launch-per-step fused select beyond / at short atoms
         A = int(rng.choice([1000, 1024, 1500])); L = int(rng.choice([32, 64, 600])); N = int(rng.integers(36000, 48000)); B = 2; K = 3
     if case % 10 == 4:   # atoms beyond 5398 samples: split transforms (two 2^14-point halves per 2^15-point transform)
         A = int(rng.integers(1, 10)); L = int(rng.choice([5399, 8192, 10859])); N = int(rng.integers(L // 2, 30000)); B = int(rng.choice([1, 2, 9])); K = 3

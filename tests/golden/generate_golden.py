@@ -514,8 +514,190 @@ def config3_fixture(mp, norm, K=16, n_ev=48):
           f"lags {out['lag'].tolist()}")
 
 
+def _reference_model_namespace(picks):
+    """class MatchingPursuit (mp.py:32-67) and modules/transfer.py:548-569 fft_convolve from their ASTs (mp.py itself
+    imports conjure / matplotlib-Qt / data), with sparsify2 wrapped to record every step's top-2 values."""
+    import functools
+    from torch import nn as _nn
+    from torch.nn import functional as _F
+    sparse_mod = importlib.import_module("modules.sparse")
+
+    def sparsify2_recording(x, n_to_keep=8):
+        out = sparse_mod.sparsify2(x, n_to_keep=n_to_keep)
+        flat = x.reshape(x.shape[0], -1)
+        v, idx = torch.topk(flat, k=2, dim=-1)
+        picks.append((idx[:, 0] // x.shape[-1], idx[:, 0] % x.shape[-1], v.detach().clone(), idx.detach().clone()))
+        return out
+
+    tr_src = ast.parse(open(os.path.join(REF, "modules", "transfer.py")).read())
+    fc = [n for n in tr_src.body if isinstance(n, ast.FunctionDef) and n.name == "fft_convolve"]
+    mp_src = ast.parse(open(os.path.join(REF, "mp.py")).read())
+    cls = [n for n in mp_src.body if isinstance(n, ast.ClassDef) and n.name == "MatchingPursuit"]
+    ns = {"torch": torch, "nn": _nn, "F": _F, "reduce": functools.reduce, "sparsify2": sparsify2_recording}
+    exec(compile(ast.Module(body=fc + cls, type_ignores=[]), "mp.py<extract>", "exec"), ns)
+    return ns
+
+
+def model_full_fixture(stft_mod, itns):
+    """The gradient-trained model at mp.py:92's REAL configuration -- MatchingPursuit(n_atoms=128, atom_samples=1024,
+    n_samples=2**15, n_iterations=25), batch 1, loss = iterative_loss(target, recon, stft(x, 2048, 256, pad=True))
+    (mp.py:68-70, 104) -- forward channels, per-step picks with their top-2 values, loss and d loss / d atoms.  Atoms are
+    drawn as mp.py:41 draws them (uniform(-0.01, 0.01)) from numpy's PCG64 and stored; the target is one synthetic
+    segment (events of a 128 x 1024 dictionary on the harmonic bed, mpcore/synth.py), peak-normalised as AudioIterator
+    (normalize=True) does.  The channels are sparse (one scaled atom each) and compress to ~100 KB."""
+    A_, L_, N_, K_, B_ = 128, 1024, 2 ** 15, 25, 1
+    picks = []
+    ns = _reference_model_namespace(picks)
+    rng = np.random.Generator(np.random.PCG64(2121))
+    atoms0 = rng.uniform(-0.01, 0.01, (1, A_, L_)).astype(np.float32)
+    dsyn = synth.make_dictionary(A_, L_, seed=2121)
+    target = synth.make_segments(B_, N_, dsyn, n_events=40, seed=2122)
+    model = ns["MatchingPursuit"](n_atoms=A_, atom_samples=L_, n_samples=N_, n_iterations=K_)
+    with torch.no_grad():
+        model.atoms.copy_(torch.from_numpy(atoms0))
+    tt = torch.from_numpy(target)[:, None, :]
+    channels = model.forward(tt)
+
+    def transform(t):
+        return stft_mod.stft(t, 2048, 256, pad=True)
+
+    loss = itns["iterative_loss"](tt, channels, transform)
+    loss.backward()
+    top2 = np.stack([p[2].numpy() for p in picks], 1)            # [B, K, 2]
+    gap = (top2[..., 0] - top2[..., 1]) / np.abs(top2[..., 0])
+    # a channel is ONE scaled atom at one position (plus the irfft's rounding noise everywhere else, ~1e-9, which does not
+    # compress): the fixture keeps each channel's L-sample window at its pick and the largest |value| outside it
+    ch = channels.detach().numpy()
+    ptime = np.stack([p[1].numpy() for p in picks], 1)
+    win = np.zeros((B_, K_, L_), dtype=np.float32)
+    outside = np.zeros((B_, K_), dtype=np.float32)
+    for b in range(B_):
+        for k in range(K_):
+            t0 = int(ptime[b, k])
+            n_in = min(L_, N_ - t0)
+            win[b, k, :n_in] = ch[b, k, t0:t0 + n_in]
+            rest = ch[b, k].copy()
+            rest[t0:t0 + n_in] = 0
+            outside[b, k] = np.abs(rest).max()
+    np.savez_compressed(os.path.join(HERE, "mp_model_full.npz"), atoms_seed=np.int64(2121),
+                        atoms_sum=np.float64(atoms0.astype(np.float64).sum()),
+                        atoms_abs_sum=np.float64(np.abs(atoms0.astype(np.float64)).sum()), atoms_head=atoms0[0, :2],
+                        shape=np.array([A_, L_, N_, K_, B_], dtype=np.int64), target=target,
+                        channel_windows=win, channel_outside_max=outside, channel_abs_max=np.float32(np.abs(ch).max()),
+                        loss=np.float64(loss.item()), atoms_grad=model.atoms.grad.numpy(),
+                        pick_atom=np.stack([p[0].numpy() for p in picks], 1),
+                        pick_time=np.stack([p[1].numpy() for p in picks], 1),
+                        pick_top2=top2, pick_top2_index=np.stack([p[3].numpy() for p in picks], 1),
+                        n_iterations=np.int64(K_), stft=np.array([2048, 256], dtype=np.int64))
+    print(f"  mp_model_full: loss {loss.item():.6f}; min relative top-2 gap {gap.min():.3e}; steps below 1e-4: "
+          f"{int((gap < 1e-4).sum())} of {gap.size}; |grad| max {float(model.atoms.grad.abs().max()):.3e}")
+
+
+BAND_TABLE = [(512, 128), (1024, 256), (2048, 512), (4096, 1024), (8192, 2048), (16384, 4096), (32768, 8192)]
+
+
+def band_table_signal(n, seed=3131):
+    """One 32768-sample signal with structure in every octave band: white noise at -26 dB plus decaying sinusoids from 60
+    Hz to 9 kHz at random onsets, peak-normalised (numpy PCG64; stored with the fixture)."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    t = np.arange(n, dtype=np.float64)
+    x = 0.05 * rng.standard_normal(n)
+    for f0 in (60., 130., 250., 520., 900., 1700., 2500., 4200., 6000., 9000.):
+        for _ in range(2):
+            on = int(rng.integers(0, n - n // 8))
+            tau = float(rng.uniform(400., 4000.))
+            amp = float(rng.uniform(0.3, 1.0))
+            x += amp * np.sin(2 * np.pi * f0 / 22050. * (t - on) + rng.uniform(0, 6.28)) * np.exp(-np.maximum(t - on, 0) / tau) * (t >= on)
+    return (x / np.abs(x).max()).astype(np.float32)[None, :]
+
+
+def multiband_full_fixture(mp, norm, steps=3, n_atoms=1024):
+    """MultibandDictionaryLearning on the band table of experiments/archive/e_2023_3_8/experiment.py:351-359 -- seven bands
+    of 512 .. 32768 samples, 1024 atoms each of band / 4 samples (128 .. 8192: the two longest bands are the split
+    transforms of the FFT schedule) -- batch 1, `steps` steps per band: every band's picks in selection order with the
+    top-2 values of the reference's own map (recorded through sparse_code's visit_key_point hook, which BandSpec.encode
+    does not pass itself), the global event tuples, decode(encode(x)) and recon(x).  The 66 MB of dictionaries are NOT
+    stored: band i's is synth.make_dictionary(1024, L, seed 4000 + i) (numpy PCG64) through the reference's unit_norm;
+    the fixture keeps float64 checksums and the first two rows of each."""
+    zs = types.ModuleType("zounds")
+    zs.SampleRate = object
+    zs.SR22050 = lambda: None
+    sys.modules["zounds"] = zs
+    mb = importlib.import_module("modules.multibanddict")
+    n = 32768
+    x = band_table_signal(n)
+    xt = torch.from_numpy(x)[:, None, :]
+    rec_picks = {}
+    real_sparse_code = mb.sparse_code
+
+    def recording_sparse_code(batch, d, n_steps, **kw):
+        size = batch.shape[-1]
+        log = rec_picks.setdefault(size, [])
+
+        def visit(fm, ai, p, a):
+            top = torch.topk(fm.reshape(-1), 2)
+            log.append((int(ai), int(p), float(fm[ai, int(p)]), top.values.numpy().copy(), top.indices.numpy().copy()))
+        if kw.get("extract_atom_embedding") is None:
+            kw["visit_key_point"] = visit
+        return real_sparse_code(batch, d, n_steps, **kw)
+
+    mb.sparse_code = recording_sparse_code
+    try:
+        specs = []
+        sums = {}
+        for i, (size, L) in enumerate(BAND_TABLE):
+            spec = mb.BandSpec(size, n_atoms=n_atoms, atom_size=L, signal_samples=n, is_lowest_band=(i == 0))
+            spec.d = norm.unit_norm(torch.from_numpy(synth.make_dictionary(n_atoms, L, seed=4000 + i)))
+            du = spec.d.numpy()
+            sums[f"d_unit_sum_{size}"] = np.float64(du.astype(np.float64).sum())
+            sums[f"d_unit_abs_sum_{size}"] = np.float64(np.abs(du.astype(np.float64)).sum())
+            sums[f"d_unit_head_{size}"] = du[:2].astype(np.float32)
+            specs.append(spec)
+        model = mb.MultibandDictionaryLearning(specs, n)
+        with torch.no_grad():
+            enc = model.encode(xt, steps=steps)
+            picks_first = {k: list(v) for k, v in rec_picks.items()}     # (recon() below encodes once more)
+            flat = model.flattened_event_tuples(enc)
+            rec = model.decode(enc)
+            rec2, _ = model.recon(xt, steps=steps)
+    finally:
+        mb.sparse_code = real_sparse_code
+    out = dict(signal=x, steps=np.int64(steps), n_atoms=np.int64(n_atoms),
+               sizes=np.array([s for s, _ in BAND_TABLE], dtype=np.int64),
+               atom_sizes=np.array([l for _, l in BAND_TABLE], dtype=np.int64),
+               seeds=np.array([4000 + i for i in range(len(BAND_TABLE))], dtype=np.int64),
+               flat_global=np.array([[e[0], e[1]] for e in flat], dtype=np.int64),
+               flat_time=np.array([float(e[2]) for e in flat], dtype=np.float64),
+               flat_amp=np.array([float(e[3]) for e in flat], dtype=np.float32),
+               recon=rec.numpy(), recon2=rec2.numpy(), **sums)
+    worst = 1.0
+    for size, log in picks_first.items():
+        out[f"pick_atom_{size}"] = np.array([e[0] for e in log], dtype=np.int64)
+        out[f"pick_lag_{size}"] = np.array([e[1] for e in log], dtype=np.int64)
+        out[f"pick_gain_{size}"] = np.array([e[2] for e in log], dtype=np.float32)
+        top2 = np.array([e[3] for e in log], dtype=np.float32)
+        out[f"pick_top2_{size}"] = top2
+        out[f"pick_top2_index_{size}"] = np.array([e[4] for e in log], dtype=np.int64)
+        g = float(((top2[:, 0] - top2[:, 1]) / np.abs(top2[:, 0])).min())
+        worst = min(worst, g)
+        print(f"    band {size}: picks {out[f'pick_atom_{size}'].tolist()} at {out[f'pick_lag_{size}'].tolist()}, min gap {g:.3e}")
+    np.savez_compressed(os.path.join(HERE, "multiband_e_2023_3_8.npz"), **out)
+    print(f"  multiband_e_2023_3_8: {len(flat)} events, min relative top-2 gap over the bands {worst:.3e}, "
+          f"recon error energy {float(((xt - rec) ** 2).sum() / (xt ** 2).sum()):.4f}")
+
+
 if __name__ == "__main__":
-    if len(sys.argv) > 1 and sys.argv[1] == "loss":  # only the loss / approximate-correlation fixtures
+    if len(sys.argv) > 1 and sys.argv[1] == "model_full":   # mp.py:92's real configuration
+        torch.manual_seed(0)
+        torch.set_num_threads(8)
+        _mp, _conv, _norm, _stft, _ns = load_reference()
+        model_full_fixture(_stft, _ns)
+    elif len(sys.argv) > 1 and sys.argv[1] == "bands":      # the e_2023_3_8 band table
+        torch.manual_seed(0)
+        torch.set_num_threads(8)
+        _mp, _conv, _norm, _stft, _ns = load_reference()
+        multiband_full_fixture(_mp, _norm)
+    elif len(sys.argv) > 1 and sys.argv[1] == "loss":  # only the loss / approximate-correlation fixtures
         torch.manual_seed(0)
         torch.set_num_threads(8)
         _mp, _conv, _norm, _stft, _ns = load_reference()

@@ -79,14 +79,34 @@ def test_torch_cpu_restatement_matches_reference_and_oracle(oracle, golden_dir, 
     assert rate > 0 and dt > 0
 
 
+def test_oracle_matches_reference_at_the_headline_depth(oracle, golden_dir):
+    """configs[1]'s shape at the headline's depth -- 512 x 512 dictionary, 32768-sample segments, K = 64 -- against the
+    reference's own sparse_code (modules/matchingpursuit.py:269-328), one seed, near-ties kept: the fixture's 256
+    segment-steps hold four with a relative top-2 gap below 1e-4 (smallest 9.5e-6) and 37 below 1e-3.  Here the first two
+    segments x 64 steps (~20 s on 8 threads; the GPU suite walks all four against both the oracle and the fixture).  The
+    report is printed (pytest -s) and sits in any failure's message."""
+    import near_ties
+    z = np.load(os.path.join(golden_dir, "encode_c2shape_512x512_n32768_b4_k64.npz"))
+    du = oracle.unit_norm(_raw_dict(z))
+    assert np.abs(du - z["d_unit"]).max() <= 2e-7
+    B, K = 2, z["atom"].shape[1]
+    assert K == 64 and (near_ties.gaps(z) < near_ties.NEAR_TIE).sum() >= 1      # the fixture does hold near-ties
+    out = oracle.encode(z["signal"][:B], du, K)
+    rep = near_ties.compare(z, out, segments=B)
+    print(near_ties.describe("oracle, headline depth", rep))
+    assert rep["compared_steps"] + len(rep["took_runner_up"]) >= K        # (at least one whole trajectory was walked)
+    # the reference's FFT branch (conv.py:11-53) made the same picks as its direct branch at every one of the 256 steps
+    assert np.array_equal(z["fft_atom"], z["atom"]) and np.array_equal(z["fft_lag"], z["lag"])
+
+
 LCN_GOLDEN = ["encode_lcn_24x100_n1000_b2_k10", "encode_lcn_64x128_n4096_b3_k12", "encode_lcn_7x33_n300_b2_k6"]
 
 
 def test_oracle_matches_reference_at_the_config3_shape(oracle, golden_dir):
     """BASELINE configs[3]'s shape (4096 x 2048 dictionary, 131072-sample segments): the oracle against the reference's
-    own sparse_code at that size -- both segments, the first two of the fixture's four steps (~25 s on 8 CPUs; the GPU
-    suite walks all four).  The dictionary is regenerated from its seed and checked against the fixture's checksums."""
-    z = np.load(os.path.join(golden_dir, "encode_c4shape_4096x2048_n131072_b2_k4.npz"))
+    own sparse_code at that size -- both segments, the first two of the fixture's sixteen steps (~25 s on 8 CPUs; the GPU
+    suite walks all sixteen against the fixture and six against the oracle).  The dictionary is regenerated from its seed and checked against the fixture's checksums."""
+    z = np.load(os.path.join(golden_dir, "encode_c4shape_4096x2048_n131072_b2_k16.npz"))
     A, L, N, B, K = [int(v) for v in z["shape"]]
     du = oracle.unit_norm(synth.make_dictionary(A, L, seed=int(z["seed"])))
     assert abs(du.astype(np.float64).sum() - float(z["d_unit_sum"])) <= 1e-4
