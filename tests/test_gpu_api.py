@@ -582,14 +582,18 @@ def test_gradient_trained_model_at_the_reference_configuration(golden_dir):
         rest[t0:t0 + n_in] = 0
         assert np.abs(rest).max() <= 5e-5 * scale and float(z["channel_outside_max"][0, k]) <= 5e-5 * scale, k
     loss = iterative_loss(target, channels, _reference_stft_flat(ws, step))
-    assert abs(loss.item() - float(z["loss"])) <= 1e-4 * abs(float(z["loss"]))
+    # (the loss is a DIFFERENCE of L1 norms of whole spectrograms, |T - sum S|_1 - |T|_1: fp32 summation noise scales
+    #  with |T|_1, not with the difference -- 3e-6 |T|_1 is a few ulps of the sums the reference itself forms)
+    t_norm = float(_reference_stft_flat(ws, step)(target).abs().sum())
+    loss_tol = 1e-4 * abs(float(z["loss"])) + 3e-6 * t_norm
+    assert abs(loss.item() - float(z["loss"])) <= loss_tol, (loss.item(), float(z["loss"]), t_norm)
     loss.backward()
     g_dense = model.atoms.grad.clone()
     gscale = np.abs(z["atoms_grad"]).max()
     assert np.abs(g_dense.cpu().numpy() - z["atoms_grad"]).max() <= 2e-3 * gscale
     model.atoms.grad = None
     ev = stft_iterative_loss(model, target, ws, step)
-    assert abs(ev.item() - float(z["loss"])) <= 1e-4 * abs(float(z["loss"]))
+    assert abs(ev.item() - float(z["loss"])) <= loss_tol, (ev.item(), float(z["loss"]), t_norm)
     ev.backward()
     assert np.abs(model.atoms.grad.cpu().numpy() - z["atoms_grad"]).max() <= 2e-3 * gscale
 
