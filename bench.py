@@ -752,6 +752,90 @@ def lcn_variant(x, du, steps):
     return res
 
 
+def multi_rank_fields(x, d, dt_max, steps, rank, world, dev, group):
+    """N > 1 only: what the first real multi-GPU lease should yield in one run -- how many ranks took
+    part and on which devices, every rank's own encode rate (its timed region, before the max over ranks), and the two
+    collectives of the surface at their own shapes: dictionary_learning_step with its per-level [atoms in level, L]
+    all-reduce over all ranks' segments (configs[2]'s batch: 64 segments per rank), and one training step of the mp.py
+    model with its [A, L] gradient all-reduce (configs[4]: 8 segments per rank).  A failure in either is reported as a
+    string, never raised: the encode line above stands on its own."""
+    import torch.distributed as tdist
+    import mpcore.matchingpursuit as mpm
+    from mpcore.model import MatchingPursuit, train_step
+    out = {}
+    mine = torch.tensor([float(rank), float(torch.cuda.current_device()), float(B_PER_GPU * K_ITERS * steps)], dtype=torch.float64, device=dev)
+    # (a rank's own elapsed time is not kept by timed_encodes -- its barrier makes them equal; the per-rank rate is from one more
+    #  un-barriered encode batch)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    du = nat.unit_norm(torch.from_numpy(d).to(dev))
+    for _ in range(steps):
+        nat.encode(x, du, K_ITERS, path=nat.MP_PATH_FFT)
+    torch.cuda.synchronize()
+    own = torch.tensor([B_PER_GPU * K_ITERS * steps / (time.perf_counter() - t0)], dtype=torch.float64, device=dev)
+    try:
+        rows, _ = mpdist.gather_batch(torch.cat([mine, own])[None, :], group)
+        rows = rows.cpu().tolist()
+        out["ranks_seen"] = len({int(r[0]) for r in rows})
+        out["devices_seen"] = sorted({int(r[1]) for r in rows})
+        out["per_rank_seg_it_s"] = [round(r[3], 1) for r in sorted(rows)]
+    except Exception as e:  # noqa: BLE001
+        out["ranks_seen"] = f"all_gather failed: {type(e).__name__}: {e}"[:200]
+    try:
+        d_raw = torch.from_numpy(d).to(dev)
+        x3 = x[:, None, :]
+        mpm.dictionary_learning_step(x3, d_raw, n_steps=K_ITERS, process_group=tdist.group.WORLD)
+        torch.cuda.synchronize()
+        mpdist.barrier(group)
+        t0 = time.perf_counter()
+        reps = 3
+        for _ in range(reps):
+            d_new = mpm.dictionary_learning_step(x3, d_raw, n_steps=K_ITERS, process_group=tdist.group.WORLD)
+        torch.cuda.synchronize()
+        mpdist.barrier(group)
+        ms = torch.tensor([(time.perf_counter() - t0) / reps * 1e3], dtype=torch.float64, device=dev)
+        ms = mpdist.all_reduce_max(ms, group)
+        chk = torch.tensor([float(d_new.double().sum())], dtype=torch.float64, device=dev)
+        hi, lo = mpdist.all_reduce_max(chk.clone(), group), -mpdist.all_reduce_max(-chk.clone(), group)
+        out["dls_by_levels_ms"] = round(float(ms.item()), 3)
+        out["dls_by_levels"] = {"segments_all_ranks": world * B_PER_GPU, "iterations": K_ITERS,
+                                "same_dictionary_on_every_rank": bool(lo.item() == hi.item()),
+                                "note": "dictionary_learning_step(process_group=WORLD): encode of the rank's shard + one "
+                                        "[atoms in level, L] fp64 all-reduce per dependency level"}
+    except Exception as e:  # noqa: BLE001
+        out["dls_by_levels_ms"] = f"failed: {type(e).__name__}: {e}"[:300]
+    try:
+        A5, L5, N5, B5, K5 = 512, 512, 32768, 8, 32
+        torch.manual_seed(0)
+        m5 = MatchingPursuit(A5, L5, N5, K5).to(dev)
+        d5 = synth.make_dictionary(A5, L5, seed=5000)
+        with torch.no_grad():
+            m5.atoms.copy_(torch.from_numpy(d5)[None].to(dev) * 0.05)
+        opt = torch.optim.Adam(m5.parameters(), lr=1e-3)
+        x5 = torch.from_numpy(synth.make_segments(B5, N5, d5, n_events=3 * K5, seed=5001, first_index=rank * B5)).to(dev)[:, None, :]
+        for _ in range(2):
+            train_step(m5, opt, x5, ("stft", 2048, 256), tdist.group.WORLD)
+        torch.cuda.synchronize()
+        mpdist.barrier(group)
+        t0 = time.perf_counter()
+        reps = 5
+        for _ in range(reps):
+            train_step(m5, opt, x5, ("stft", 2048, 256), tdist.group.WORLD)
+        torch.cuda.synchronize()
+        mpdist.barrier(group)
+        ms = mpdist.all_reduce_max(torch.tensor([(time.perf_counter() - t0) / reps * 1e3], dtype=torch.float64, device=dev), group)
+        chk = m5.atoms.detach().double().sum().reshape(1)
+        hi, lo = mpdist.all_reduce_max(chk.clone(), group), -mpdist.all_reduce_max(-chk.clone(), group)
+        out["config5_train_step_ms"] = round(float(ms.item()), 3)
+        out["config5_train_step"] = {"segments_all_ranks": world * B5, "seg_it_s_all_ranks": round(world * B5 * K5 / (float(ms.item()) * 1e-3), 1),
+                                     "same_atoms_on_every_rank": bool(lo.item() == hi.item()),
+                                     "note": "mp.py model at BASELINE configs[4]'s shape, 8 segments per rank; one all-reduce of the "
+                                             "[512, 512] gradient per step (mpcore.model.all_reduce_gradients), identical Adam on every rank"}
+    except Exception as e:  # noqa: BLE001
+        out["config5_train_step_ms"] = f"failed: {type(e).__name__}: {e}"[:300]
+    return out
+
+
 def _free_port():
     with socket.socket() as sock:
         sock.bind(("127.0.0.1", 0))
@@ -927,6 +1011,42 @@ def main():
             if not args.no_configs3:
                 nat.profile_enable(PROF_EVERY)
                 line["variants"]["configs3_full_size"] = configs3_variant(dev)
+            nat.profile_enable(0)
+            line["variants"]["lcn_headline"] = lcn_variant(x, du, args.steps)
+            line["variants"].update(next_rows_variants(dev, args.steps))
+        # what SURVEY.md 8(d) prices -- the DIRECT schedule's 17.18 GFLOP per segment-iteration on the matrix core -- and
+        # configs[3] go INTO `roofline` (the part of the line the driver's record keeps): a short direct encode if the
+        # variants leg did not run one
+        direct = (line.get("variants") or {}).get("direct_full_recompute_mfma")
+        if direct is None and path != nat.MP_PATH_DIRECT:
+            nat.profile_enable(PROF_EVERY)
+            ddt, dout, dprof = timed_encodes(x, du, 1, 0, nat.MP_PATH_DIRECT, nat.MP_FLAG_NO_OVERLAP, group)
+            direct = {"value": round(B_PER_GPU * K_ITERS / ddt, 2), "ms_per_step": round(ddt * 1e3, 4), "steps": 1,
+                      "bit_identical_to_headline": bool(all(torch.equal(p, q) for p, q in zip(dout, out))),
+                      "roofline": roofline_from(dprof, algorithmic_flops(dout[1].cpu().numpy(), nat.MP_PATH_DIRECT), 1)}
+            nat.profile_enable(0)
+        if direct is not None and roof is not None and direct.get("roofline"):
+            dr = direct["roofline"]
+            roof["direct_path"] = {
+                "seg_it_s": direct["value"], "tflops": dr["achieved"], "frac": dr["frac"], "bound": "mfma",
+                "peak_tflops": dr["peak"], "kernel": dr["kernel"], "avg_launch_ms": dr["avg_launch_ms"],
+                "algorithmic_gflop_per_segment_iteration": round(2.0 * A * L * N / 1e9, 3),
+                "traffic": dr.get("traffic"), "bit_identical_to_headline": direct["bit_identical_to_headline"],
+                "note": "MP_PATH_DIRECT: every cell of the A x N plane recomputed every step on v_mfma_f32_32x32x2_f32 -- the "
+                        "schedule that does SURVEY 8(d)'s 2 A L N flop per segment-iteration; the headline's FFT screen + exact "
+                        "refinement produces the same events bit for bit with ~1/165 of that work"}
+        c3 = (line.get("variants") or {}).get("configs3_full_size")
+        if c3 is not None and roof is not None and c3.get("roofline"):
+            cr = c3["roofline"]
+            roof["configs3"] = {
+                "workload": c3["workload"], "seg_it_s": c3["value"], "ms_per_encode": c3["ms_per_step"],
+                "kernel": cr["kernel"], "bound": "valu", "frac": cr["frac"], "frac_issue": cr["frac_issue"],
+                "frac_flops": cr["frac_flops"], "frac_from_pmc": cr.get("frac_from_pmc"), "tflops": cr["tflops"],
+                "min_valu_per_thread_transform": cr["min_valu"]["per_thread_transform"],
+                "valu_per_thread_transform": cr["valu_per_thread_transform"],
+                "avg_launch_ms": cr["avg_launch_ms"], "traffic": cr["traffic"], "frac_hbm": cr.get("frac_hbm"),
+                "survey_8d_equivalent_gbs": cr.get("survey_8d_equivalent_gbs"),
+                "timed_on": "one-stream encode (the default's four sub-batches overlap their launches)"}
         if not args.no_cpu:
             base, parity = cpu_baseline(d, x_host, (atom, lag, gain))
             line["cpu_baseline"] = base
@@ -934,6 +1054,12 @@ def main():
             line["speedup_vs_cpu_baseline"] = round(line["value"] / base["value"], 1)
             line["cpu_baseline_torch_ops"] = cpu_baseline_torch(d, x_host, (atom, lag, gain))
     nat.profile_enable(False)
+    if world > 1:
+        line.update(multi_rank_fields(x, d, dt, args.steps, rank, world, dev, group))
+    if rank == 0 and line.get("variants"):
+        # (the driver's record keeps the standard keys and the TAIL of stdout: one compact line per variant goes last)
+        line["variants_summary"] = {k: [v.get("value"), v.get("unit", "")[:28], v.get("ms_per_step", v.get("encode_ms"))]
+                                    for k, v in line["variants"].items() if isinstance(v, dict)}
     if rank == 0:
         print(json.dumps(line), flush=True)
     if world > 1:
