@@ -384,6 +384,29 @@ __device__ __forceinline__ u64 cell_key(f32x16 (&acc)[2][TA / 32], int tile, int
 }
 
 // ------------------------------------------------------------------------------------------------
+// Cell-order map (the local-contrast-norm schedule's dense map, TA = 32): cell (b, blk, tile) keeps its 32 atoms x 64 lags
+// as 2048 floats in ACCUMULATOR order -- float4 number (s * 4 + rq) * 64 + lane holds registers r = 4 rq .. 4 rq + 3 of
+// sub-tile s of lane (i = lane & 31, h = lane >> 5), i.e. atom i, lags s * 32 + 8 rq + 4 h + (0 .. 3).  A wavefront
+// stores its finished cell with eight 1 KiB-contiguous instructions (the [B, A, N] layout takes 64 strided 4-byte
+// rows per instruction); readers un-permute with cell_map_offset.
+// ------------------------------------------------------------------------------------------------
+constexpr int CELL_FLOATS = 32 * LAGS_PER_WAVE;
+__host__ __device__ __forceinline__ int cell_map_offset(int i, int dl) {   // atom i of the tile, lag dl of the block
+    const int s = dl >> 5, d32 = dl & 31;
+    return (((s * 4 + (d32 >> 3)) * 64 + i + 32 * ((d32 >> 2) & 1)) << 2) + (d32 & 3);
+}
+__device__ __forceinline__ void store_cell_map(float *__restrict__ cell, const f32x16 (&acc)[2][1], int lane) {
+    f32x4 *dst = reinterpret_cast<f32x4 *>(cell);
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+        for (int rq = 0; rq < 4; ++rq) {
+            const f32x4 q = {acc[s][0][4 * rq], acc[s][0][4 * rq + 1], acc[s][0][4 * rq + 2], acc[s][0][4 * rq + 3]};
+            dst[(s * 4 + rq) * 64 + lane] = q;
+        }
+}
+
+// ------------------------------------------------------------------------------------------------
 // Correlate: one wavefront = one cell task (segment b, 64-lag block, atom tile); the 4 wavefronts of a
 // workgroup take 4 consecutive tasks of the SAME atom tile (so they share the staged dictionary
 // image) from the flattened list  task = b * stride + c,  c-th block of segment b's dirty run
@@ -397,7 +420,8 @@ __device__ __forceinline__ u64 cell_key(f32x16 (&acc)[2][TA / 32], int tile, int
 // Every product chain is ascending in k: bit-identical to the oracle's fmaf chain.
 // STORE_FM: additionally write the dense map (hooks that need it); keys are still produced.
 // ------------------------------------------------------------------------------------------------
-template <int TA, bool STORE_FM, bool DMA>
+// CELLMAP (TA = 32 only): `fm` is the cell-order map above and no keys are written (the LCN schedule has its own).
+template <int TA, bool STORE_FM, bool DMA, bool CELLMAP = false>
 __global__ __launch_bounds__(256) void correlate_mfma_kernel(
     const float *__restrict__ res, const float *__restrict__ img, const int *__restrict__ dirty,
     u64 *__restrict__ keys, float *__restrict__ fm, int64_t N, int64_t A, int64_t Ns, int64_t B, int NBLK,
@@ -456,6 +480,11 @@ __global__ __launch_bounds__(256) void correlate_mfma_kernel(
     }
     if (!active) return;
 
+    if constexpr (CELLMAP) {
+        static_assert(!CELLMAP || TA == 32, "the cell-order map is for 32-atom tiles");
+        store_cell_map(fm + ((b * NBLK + blk) * NAT + tile) * CELL_FLOATS, acc, lane);
+        return;
+    }
     const u64 key = cell_key<TA>(acc, tile, t0, N, A, i, h);
     if (lane == 0) keys[(b * NBLK + blk) * NAT + tile] = key;
 
@@ -485,11 +514,11 @@ __global__ __launch_bounds__(256) void correlate_mfma_kernel(
 // of a tile ONCE and its four wavefronts then pull that range's cell tasks from an LDS counter, so a
 // wavefront never waits for another between cells and staging is amortised over many cells.
 // ------------------------------------------------------------------------------------------------
-template <int TA, bool DMA>
+template <int TA, bool DMA, bool CELLMAP = false>
 __global__ __launch_bounds__(256) void correlate_persistent_kernel(
     const float *__restrict__ res, const float *__restrict__ img, const int *__restrict__ dirty,
     u64 *__restrict__ keys, int64_t N, int64_t A, int64_t Ns, int NBLK, int NAT, int KC, int stride,
-    int64_t LT, int64_t tasks_per_wg, int stagger) {
+    int64_t LT, int64_t tasks_per_wg, int stagger, float *__restrict__ cmap /* CELLMAP: the cell-order map; else unused */) {
     constexpr int NT = TA / 32;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float *img_s = reinterpret_cast<float *>(smem);  // KC * TA floats
@@ -584,8 +613,12 @@ __global__ __launch_bounds__(256) void correlate_persistent_kernel(
 #pragma unroll
                         for (int r = 0; r < 16; ++r) acc[s][nt][r] = 0.0f;
                 mfma_chunk<TA>(img_s, win_s, KC, i, h, acc);
-                const u64 key = cell_key<TA>(acc, tile, t0, N, A, i, h);
-                if (lane == 0) keys[(b * NBLK + blk) * NAT + tile] = key;
+                if constexpr (CELLMAP) {
+                    store_cell_map(cmap + ((b * NBLK + blk) * NAT + tile) * CELL_FLOATS, acc, lane);
+                } else {
+                    const u64 key = cell_key<TA>(acc, tile, t0, N, A, i, h);
+                    if (lane == 0) keys[(b * NBLK + blk) * NAT + tile] = key;
+                }
             }
         }
         __syncthreads();  // every wavefront is done with this image (and with the counter)
@@ -756,19 +789,25 @@ __global__ __launch_bounds__(256) void conv_model_backward_kernel(
 // over the dense (A, N) map, and its gain is the RAW map value there (:294).  avg is ONE sequential fp32 sum
 // over the window in row-major order (a' ascending, then t' ascending; zeros outside the map add nothing)
 // divided by 81 -- ATen's cpu_avg_pool2d loop, restated in oracle/mp_oracle.c:mpo_encode_lcn.
-// The map itself is kept in HBM and only its dirty 64-lag blocks are recomputed each step (the MFMA
-// correlate with STORE_FM); this kernel then redoes the LCN keys of those blocks and one block either side
-// (the box reaches 4 lags across a block edge).  One workgroup = one LCN cell of 16 atoms x 64 lags, staged
-// with its halo (24 x 72 floats) in LDS; a wavefront's 64 lanes read 64 consecutive floats of one row, so the
-// 81 LDS reads per output are conflict-free.
+// The map is kept in HBM in CELL ORDER (above) and only its dirty 64-lag blocks are recomputed each step (the MFMA
+// correlate, persistent form, storing cells instead of keys); this kernel then redoes the LCN keys of those blocks and one
+// block either side (the box reaches 4 lags across a block edge).  One workgroup = one map cell of 32 atoms x 64 lags,
+// staged with its halo (40 x 72 floats) in LDS: the cell itself by 1 KiB-contiguous loads, the halo's 832 values gathered
+// from the eight neighbouring cells.  A wavefront's 64 lanes read 64 consecutive floats of one row (row stride 73 words),
+// so the LDS reads are conflict-free; the four rows a wavefront walks together share nine of their twelve box rows.
 // ------------------------------------------------------------------------------------------------
-constexpr int LCN_TA = 16;
+constexpr int LCN_ROWS = 32 + 8;
 constexpr int LCN_W = LAGS_PER_WAVE + 8;
 
-__global__ __launch_bounds__(256) void lcn_keys_kernel(const float *__restrict__ fm, const int *__restrict__ dirty,
+__device__ __forceinline__ float cell_map_at(const float *__restrict__ cmap, int64_t b, int64_t a, int64_t t, int NBLK, int NAT) {
+    const int64_t cell = (b * NBLK + (t >> 6)) * NAT + (a >> 5);
+    return cmap[cell * CELL_FLOATS + cell_map_offset((int)(a & 31), (int)(t & 63))];
+}
+
+__global__ __launch_bounds__(256) void lcn_keys_kernel(const float *__restrict__ cmap, const int *__restrict__ dirty,
                                                        u64 *__restrict__ lkeys, int64_t N, int64_t A, int NBLK,
-                                                       int NLT) {
-    __shared__ float tile[LCN_TA + 8][LCN_W + 1];
+                                                       int NAT) {
+    __shared__ float tile[LCN_ROWS][LCN_W + 1];
     __shared__ u64 s_key[4];
     const int b = blockIdx.z;
     const int atile = blockIdx.y;
@@ -782,28 +821,54 @@ __global__ __launch_bounds__(256) void lcn_keys_kernel(const float *__restrict__
     const int blk = first + blockIdx.x;
     if (blk > last) return;  // uniform across the workgroup
     const int tid = threadIdx.x;
-    const int64_t a0 = (int64_t)atile * LCN_TA - 4, t0 = (int64_t)blk * LAGS_PER_WAVE - 4;
-    const float *fb = fm + (int64_t)b * A * N;
-    for (int e = tid; e < (LCN_TA + 8) * LCN_W; e += 256) {
-        const int r = e / LCN_W, c = e - r * LCN_W;
+    const int64_t a0 = (int64_t)atile * 32 - 4, t0 = (int64_t)blk * LAGS_PER_WAVE - 4;
+    // the cell itself: 512 float4 in accumulator order (atoms >= A and lags >= N hold exact zeros: a zero image row / a zero
+    // residual make zero chains)
+    {
+        const f32x4 *cb = reinterpret_cast<const f32x4 *>(cmap + (((int64_t)b * NBLK + blk) * NAT + atile) * CELL_FLOATS);
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int e = tid + 256 * u;
+            const f32x4 q = cb[e];
+            const int lane = e & 63, sr = e >> 6;
+            const int r = (lane & 31) + 4, c = (sr >> 2) * 32 + 8 * (sr & 3) + 4 * (lane >> 5) + 4;
+            tile[r][c] = q[0]; tile[r][c + 1] = q[1]; tile[r][c + 2] = q[2]; tile[r][c + 3] = q[3];
+        }
+    }
+    // the halo: 4 rows above and below (72 wide), 4 columns left and right of the 32 centre rows
+    for (int e = tid; e < 8 * LCN_W + 32 * 8; e += 256) {
+        int r, c;
+        if (e < 8 * LCN_W) {
+            r = e / LCN_W;
+            c = e - r * LCN_W;
+            if (r >= 4) r += 32;
+        } else {
+            const int e2 = e - 8 * LCN_W;
+            r = 4 + (e2 >> 3);
+            c = e2 & 7;
+            if (c >= 4) c += LAGS_PER_WAVE;
+        }
         const int64_t a = a0 + r, t = t0 + c;
-        tile[r][c] = (a >= 0 && a < A && t >= 0 && t < N) ? fb[a * N + t] : 0.0f;
+        tile[r][c] = (a >= 0 && a < A && t >= 0 && t < N) ? cell_map_at(cmap, b, a, t, NBLK, NAT) : 0.0f;
     }
     __syncthreads();
     const int w = tid >> 6, lane = tid & 63;
     u64 best = 0;
+#pragma unroll 1
+    for (int jj = 0; jj < 2; ++jj) {
 #pragma unroll
-    for (int j = 0; j < LCN_TA / 4; ++j) {
-        const int ra = w * (LCN_TA / 4) + j;  // row of the cell; tile row ra + 4 is its centre
-        float sum = 0.0f;
+        for (int j = 0; j < 4; ++j) {
+            const int ra = w * 8 + jj * 4 + j;  // row of the cell; tile row ra + 4 is its centre
+            float sum = 0.0f;
 #pragma unroll
-        for (int da = 0; da < 9; ++da)
+            for (int da = 0; da < 9; ++da)
 #pragma unroll
-            for (int dt = 0; dt < 9; ++dt) sum = __fadd_rn(sum, tile[ra + da][lane + dt]);
-        const float v = __fsub_rn(tile[ra + 4][lane + 4], div_rn_f32(sum, 81.0f));
-        const int64_t a = a0 + 4 + ra, t = t0 + 4 + lane;
-        const u64 key = (a < A && t < N) ? make_key(v, (unsigned)(a * N + t)) : 0ull;
-        best = key > best ? key : best;
+                for (int dt = 0; dt < 9; ++dt) sum = __fadd_rn(sum, tile[ra + da][lane + dt]);
+            const float v = __fsub_rn(tile[ra + 4][lane + 4], div_rn_f32(sum, 81.0f));
+            const int64_t a = a0 + 4 + ra, t = t0 + 4 + lane;
+            const u64 key = (a < A && t < N) ? make_key(v, (unsigned)(a * N + t)) : 0ull;
+            best = key > best ? key : best;
+        }
     }
     best = wave_max_u64(best);
     if (lane == 0) s_key[w] = best;
@@ -811,16 +876,16 @@ __global__ __launch_bounds__(256) void lcn_keys_kernel(const float *__restrict__
     if (tid == 0) {
 #pragma unroll
         for (int q = 1; q < 4; ++q) best = s_key[q] > best ? s_key[q] : best;
-        lkeys[((int64_t)b * NBLK + blk) * NLT + atile] = best;
+        lkeys[((int64_t)b * NBLK + blk) * NAT + atile] = best;
     }
 }
 
 // argmax over a segment's LCN keys; the gain is read from the raw map; then as select_subtract_kernel
 __global__ __launch_bounds__(256) void lcn_select_subtract_kernel(
-    const u64 *__restrict__ lkeys, int64_t n_keys, const float *__restrict__ fm, float *__restrict__ res,
+    const u64 *__restrict__ lkeys, int64_t n_keys, const float *__restrict__ cmap, float *__restrict__ res,
     const float *__restrict__ du, int *__restrict__ dirty, int64_t *__restrict__ out_atom,
     int64_t *__restrict__ out_lag, float *__restrict__ out_gain, int64_t N, int64_t A, int64_t L, int64_t Ns,
-    int K, int k) {
+    int K, int k, int NBLK, int NAT) {
     __shared__ u64 s_key[4];
     const int b = blockIdx.x;
     const int tid = threadIdx.x;
@@ -837,9 +902,9 @@ __global__ __launch_bounds__(256) void lcn_select_subtract_kernel(
 #pragma unroll
     for (int q = 1; q < 4; ++q) best = s_key[q] > best ? s_key[q] : best;
     const unsigned flat = 0xffffffffu - (unsigned)(best & 0xffffffffull);
-    const float gain = fm[(int64_t)b * A * N + flat];  // torch.gather(fm, index=mx), :294
     const int64_t atom = (int64_t)(flat / (u64)N);
     const int64_t lag = (int64_t)(flat % (u64)N);
+    const float gain = cell_map_at(cmap, b, atom, lag, NBLK, NAT);  // torch.gather(fm, index=mx), :294
     __syncthreads();  // every thread has read the map before the residual (not the map) changes: no hazard,
                       // but keep the order explicit for the next launch's readers
     if (tid == 0) {
@@ -1300,7 +1365,44 @@ int launch_persistent_t(const Geom &g, const Workspace &w, const int *dirty, int
     const int64_t per = (T + grid - 1) / grid;
     grid = (T + per - 1) / per;
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), lds, st, w.res, w.img, dirty, w.keys, g.N, g.A,
-                       g.Ns, g.NBLK, g.NAT, g.KC, stride, LT, per, stagger);
+                       g.Ns, g.NBLK, g.NAT, g.KC, stride, LT, per, stagger, (float *)nullptr);
+    HIP_TRY(hipGetLastError());
+    return MP_OK;
+}
+
+// The LCN schedule's correlate (TA = 32): cells into the cell-order map, no keys.  One k-chunk: the persistent form
+// (image staged once per workgroup, windows prefetched); longer atoms: one wavefront per cell, chunk by chunk.
+int launch_correlate_cellmap(const Geom &g, const Workspace &w, const int *dirty, float *cmap, hipStream_t st) {
+    const size_t lds = lds_bytes(g);
+    const int stride = dirty ? g.MAXC : g.NBLK;
+    static thread_local size_t configured_dev[MAX_DEVICES][2] = {{0}};
+    if (g.NCH == 1) {
+        auto kern = correlate_persistent_kernel<32, true, true>;
+        size_t &configured = configured_dev[current_device()][0];
+        if (lds > configured) {
+            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            configured = lds;
+        }
+        const int64_t LT = g.B * (int64_t)stride;
+        const int64_t T = LT * g.NAT;
+        const int wgs_per_cu = (int)(160 * 1024 / lds) < 1 ? 1 : (int)(160 * 1024 / lds);
+        int64_t grid = (int64_t)num_cus() * (wgs_per_cu > 2 ? 2 : wgs_per_cu);
+        if (grid > (T + WAVES - 1) / WAVES) grid = (T + WAVES - 1) / WAVES;
+        const int64_t per = (T + grid - 1) / grid;
+        grid = (T + per - 1) / per;
+        hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), lds, st, w.res, w.img, dirty, w.keys, g.N, g.A, g.Ns, g.NBLK,
+                           g.NAT, g.KC, stride, LT, per, dirty ? 2 : 0, cmap);
+    } else {
+        auto kern = correlate_mfma_kernel<32, true, true, true>;
+        size_t &configured = configured_dev[current_device()][1];
+        if (lds > configured) {
+            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            configured = lds;
+        }
+        const int64_t tasks = g.B * (int64_t)stride;
+        hipLaunchKernelGGL(kern, dim3((unsigned)((tasks + WAVES - 1) / WAVES), g.NAT), dim3(256), lds, st, w.res, w.img, dirty,
+                           w.keys, cmap, g.N, g.A, g.Ns, g.B, g.NBLK, g.NAT, g.KC, g.NCH, stride);
+    }
     HIP_TRY(hipGetLastError());
     return MP_OK;
 }
@@ -2296,12 +2398,11 @@ int mp_encode_conv_f32(const float *signal, int64_t B, int64_t N, const float *a
 // sparse_code(..., local_contrast_norm=True), modules/matchingpursuit.py:284-294.  Workspace = the direct
 // path's + the dense map [B, A, N] + one LCN key per (64-lag block, 16-atom tile).
 static size_t lcn_extra(const Geom &g, size_t *o_map, size_t *o_keys, size_t base) {
-    const int NLT = (int)((g.A + LCN_TA - 1) / LCN_TA);
     size_t off = (size_t)round_up((int64_t)base, 256);
-    *o_map = off;
-    off += (size_t)round_up((int64_t)((size_t)g.B * g.A * g.N * sizeof(float)), 256);
+    *o_map = off;   // the cell-order map: [B][NBLK][NAT] cells of 32 x 64 floats
+    off += (size_t)round_up((int64_t)((size_t)g.B * g.NBLK * g.NAT * CELL_FLOATS * sizeof(float)), 256);
     *o_keys = off;
-    off += (size_t)round_up((int64_t)((size_t)g.B * g.NBLK * NLT * sizeof(u64)), 256);
+    off += (size_t)round_up((int64_t)((size_t)g.B * g.NBLK * g.NAT * sizeof(u64)), 256);
     return off;
 }
 
@@ -2317,8 +2418,8 @@ int mp_encode_lcn_f32(const float *signal, int64_t B, int64_t N, const float *di
                       void *workspace, size_t workspace_bytes, void *stream) {
     int rc = check_shape(B, N, A, L, K);
     if (rc) return rc;
-    if (B > 65535 || (A + LCN_TA - 1) / LCN_TA > 65535)
-        return fail(MP_ERR_ARG, "mp_encode_lcn_f32: B and A / 16 must be <= 65535%s");
+    if (B > 65535 || (A + 31) / 32 > 65535)
+        return fail(MP_ERR_ARG, "mp_encode_lcn_f32: B and A / 32 must be <= 65535%s");
     if (B == 0) return MP_OK;
     if (!signal || !dict_unit || !workspace) return fail(MP_ERR_ARG, "null pointer%s");
     if (K > 0 && (!out_atom || !out_lag || !out_gain)) return fail(MP_ERR_ARG, "null output%s");
@@ -2330,19 +2431,18 @@ int mp_encode_lcn_f32(const float *signal, int64_t B, int64_t N, const float *di
     if (lcn_extra(g, &o_map, &o_keys, w.bytes) > workspace_bytes) return fail(MP_ERR_WORKSPACE, "workspace too small%s");
     float *map = reinterpret_cast<float *>(base + o_map);
     u64 *lkeys = reinterpret_cast<u64 *>(base + o_keys);
-    const int NLT = (int)((A + LCN_TA - 1) / LCN_TA);
     hipStream_t st = static_cast<hipStream_t>(stream);
     if ((rc = stage_inputs(g, w, MP_PATH_INCREMENTAL, signal, dict_unit, 0, st))) return rc;
     for (int k = 0; k < K; ++k) {
         const int *dirty = k == 0 ? nullptr : w.dirty;
-        if ((rc = launch_correlate<true>(g, w, dirty, map, 0, st))) return rc;
+        if ((rc = launch_correlate_cellmap(g, w, dirty, map, st))) return rc;
         const int nb = k == 0 ? g.NBLK : (g.MAXC + 2 < g.NBLK ? g.MAXC + 2 : g.NBLK);
-        hipLaunchKernelGGL(lcn_keys_kernel, dim3((unsigned)nb, (unsigned)NLT, (unsigned)B), dim3(256), 0, st, map,
-                           dirty, lkeys, N, A, g.NBLK, NLT);
+        hipLaunchKernelGGL(lcn_keys_kernel, dim3((unsigned)nb, (unsigned)g.NAT, (unsigned)B), dim3(256), 0, st, map,
+                           dirty, lkeys, N, A, g.NBLK, g.NAT);
         HIP_TRY(hipGetLastError());
         hipLaunchKernelGGL(lcn_select_subtract_kernel, dim3((unsigned)B), dim3(256), 0, st, lkeys,
-                           (int64_t)g.NBLK * NLT, map, w.res, dict_unit, w.dirty, out_atom, out_lag, out_gain, N, A, L,
-                           g.Ns, K, k);
+                           (int64_t)g.NBLK * g.NAT, map, w.res, dict_unit, w.dirty, out_atom, out_lag, out_gain, N, A, L,
+                           g.Ns, K, k, g.NBLK, g.NAT);
         HIP_TRY(hipGetLastError());
     }
     if (out_residual) {
