@@ -854,19 +854,52 @@ __global__ __launch_bounds__(256) void lcn_keys_kernel(const float *__restrict__
     __syncthreads();
     const int w = tid >> 6, lane = tid & 63;
     u64 best = 0;
-#pragma unroll 1
-    for (int jj = 0; jj < 2; ++jj) {
+    // A wavefront owns eight rows of the cell (lane = lag).  The eight box sums walk the sixteen tile rows they cover
+    // TOGETHER, top to bottom: a row's nine values are read once (144 LDS reads per eight outputs where eight separate
+    // walks read 648 -- the kernel was bound by exactly that: 160 ds_read2 per four outputs, 187 us per incremental
+    // launch at the headline shape) and added, left to right, to every sum whose box holds the row.  Each sum still sees
+    // its 81 values in the reference's order (rows ascending, then lags ascending); two neighbouring sums that both hold the
+    // row take the value in ONE v_pk_add_f32 (two IEEE additions, the operand's low half broadcast).
+    {
+        typedef float f32x2 __attribute__((ext_vector_type(2)));
+        f32x2 sum[4];
+        float centre[8];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int ra = w * 8 + jj * 4 + j;  // row of the cell; tile row ra + 4 is its centre
-            float sum = 0.0f;
+        for (int p = 0; p < 4; ++p) sum[p] = f32x2{0.0f, 0.0f};
+        const float *col = &tile[w * 8][lane];
 #pragma unroll
-            for (int da = 0; da < 9; ++da)
+        for (int rr = 0; rr < 16; ++rr) {
+            float v[9];
 #pragma unroll
-                for (int dt = 0; dt < 9; ++dt) sum = __fadd_rn(sum, tile[ra + da][lane + dt]);
-            const float v = __fsub_rn(tile[ra + 4][lane + 4], div_rn_f32(sum, 81.0f));
+            for (int dt = 0; dt < 9; ++dt) v[dt] = col[rr * (LCN_W + 1) + dt];
+            if (rr >= 4 && rr < 12) centre[rr - 4] = v[4];
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+                const int lo = 2 * p, hi = 2 * p + 1;           // outputs (rows of the cell) of this pair
+                const bool in_lo = rr >= lo && rr <= lo + 8, in_hi = rr >= hi && rr <= hi + 8;
+                if (in_lo && in_hi) {
+#pragma unroll
+                    for (int dt = 0; dt < 9; ++dt) {
+                        f32x2 src;
+                        src.x = v[dt];
+                        asm("v_pk_add_f32 %0, %1, %2 op_sel_hi:[1,0]" : "=v"(sum[p]) : "v"(sum[p]), "v"(src));
+                    }
+                } else if (in_lo) {
+#pragma unroll
+                    for (int dt = 0; dt < 9; ++dt) sum[p].x = __fadd_rn(sum[p].x, v[dt]);
+                } else if (in_hi) {
+#pragma unroll
+                    for (int dt = 0; dt < 9; ++dt) sum[p].y = __fadd_rn(sum[p].y, v[dt]);
+                }
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int ra = w * 8 + j;
+            const float sj = (j & 1) ? sum[j >> 1].y : sum[j >> 1].x;
+            const float val = __fsub_rn(centre[j], div_rn_f32(sj, 81.0f));
             const int64_t a = a0 + 4 + ra, t = t0 + 4 + lane;
-            const u64 key = (a < A && t < N) ? make_key(v, (unsigned)(a * N + t)) : 0ull;
+            const u64 key = (a < A && t < N) ? make_key(val, (unsigned)(a * N + t)) : 0ull;
             best = key > best ? key : best;
         }
     }
