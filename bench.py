@@ -745,10 +745,25 @@ def lcn_variant(x, du, steps):
     sec, out = _rate(lambda: nat.encode_lcn(x, du, K), max(1, min(steps, 3)))
     plain = nat.encode(x, du, K, path=nat.MP_PATH_FFT)
     torch.cuda.synchronize()
+    # the schedule's own roofline: it keeps the dense A x N map (in cell order) and recomputes, EXACTLY, every map value an
+    # event changes -- 2 A L flop per (atom, lag) on the fp32 matrix core; no screen can stand in for the map, because every
+    # one of the 81 values under a box enters the selection rule.  Algorithmic flop = full pass + the dirty lags of K - 1 steps.
+    total, full, inc = algorithmic_flops(out[1].cpu().numpy(), nat.MP_PATH_INCREMENTAL)
+    tfl = total / sec / 1e12
     res = {"value": round(B * K / sec, 1), "unit": "segment-iterations/s", "ms_per_step": round(sec * 1e3, 3),
            "share_of_picks_that_differ_from_the_plain_rule": round(float(((out[0] != plain[0]) | (out[1] != plain[1])).float().mean()), 4),
-           "residual_db_mean": round(float((20 * torch.log10(out[3].norm(dim=-1) / x.norm(dim=-1))).mean()), 3)}
-    res.update(nat.lcn_stats() if hasattr(nat, "lcn_stats") else {})
+           "residual_db_mean": round(float((20 * torch.log10(out[3].norm(dim=-1) / x.norm(dim=-1))).mean()), 3),
+           "roofline": {"bound": "mfma", "achieved": round(tfl, 2), "peak": PEAK_MFMA_F32_TFLOPS, "unit": "TFLOP/s",
+                        "frac": round(tfl / PEAK_MFMA_F32_TFLOPS, 4),
+                        "algorithmic_gflop_per_encode": round(total / 1e9, 1), "full_pass_gflop": round(full / 1e9, 1),
+                        "incremental_gflop": round(inc / 1e9, 1),
+                        "mfma_floor_ms": round(total / (PEAK_MFMA_F32_TFLOPS * 1e12) * 1e3, 2),
+                        "box_sum_adds_per_encode": int(81 * B * HEAD.A * (HEAD.N + (K - 1) * (2 * HEAD.L + 128))),
+                        "kernels": "correlate_persistent_kernel<32,true,true> (cells into the cell-order map), lcn_keys_kernel, "
+                                   "lcn_select_subtract_kernel; per-kernel times: profiles/r04_lcn_kernel_stats.csv",
+                        "note": "whole-encode time against the matrix-core floor of the exact map update; the LCN pass (81 "
+                                "sequential fp32 additions per map value, packed two sums per instruction) and the select "
+                                "run between the correlates, not beside them"}}
     return res
 
 
