@@ -334,6 +334,27 @@ int mp_gather_sum_groups_f32(const float *x, int64_t B, int64_t N, const int64_t
                              const int64_t *offsets, int64_t n_groups, int64_t L, double *out, void *stream);
 
 /*
+ * One dependency level of the multi-rank dictionary_learning_step in two launches around the level's all-reduce
+ * (replaces, per level, modules/matchingpursuit.py:395-396 + :400-401 and :408-415 for all atoms of the level at once;
+ * the single-device form of the same level is inside mp_dictionary_update_levels_f32).  Group g (one used atom) owns the
+ * events [offsets[g], offsets[g + 1]) of the event arrays -- absolute positions: `offsets` is the level's slice of the
+ * whole table, the event arrays are passed whole -- all of THIS rank's segments (possibly none); overlap[g] != 0
+ * (or overlap == NULL) = two of its events may share a sample: they are staged in `sparse_zeroed` ([B, N], zero on entry
+ * and on return) event after event.
+ *   addback_sum:  residual += the events' rows;  acc[g, :] = fp64 sum over the events of residual[batch, lag : lag + L]
+ *   subtract:     residual -= new_atoms[g, :] * ev_norm[e]  for every event e of g   (new_atoms [n_groups, L])
+ * The caller all-reduces acc over the ranks, normalises (mp_unit_norm_f32) and passes the result back as new_atoms.
+ */
+int mp_dictionary_level_addback_sum_f32(float *residual, float *sparse_zeroed, int64_t B, int64_t N, int64_t L,
+                                        const int64_t *offsets, int64_t n_groups, const int64_t *ev_batch,
+                                        const int64_t *ev_lag, const float *ev_rows, const int *overlap, double *acc,
+                                        void *stream);
+int mp_dictionary_level_subtract_f32(float *residual, float *sparse_zeroed, int64_t B, int64_t N, int64_t L,
+                                     const int64_t *offsets, int64_t n_groups, const int64_t *ev_batch,
+                                     const int64_t *ev_lag, const float *ev_norm, const int *overlap,
+                                     const float *new_atoms, void *stream);
+
+/*
  * Backward pass of mp_encode_conv_f32, i.e. of the analysis loop of the reference's gradient-trained model
  * (mp.py:54-66: what loss.backward() at mp.py:104 does to it), in one launch: given the events of the forward pass
  * (atom_idx, time_idx, value [B, K]), the residual it ended with [B, N] and the gradient arriving at the K event

@@ -1018,6 +1018,104 @@ __global__ void gather_sum_groups_kernel(const float *__restrict__ x, int64_t N,
 }
 
 // ------------------------------------------------------------------------------------------------
+// One dependency level of dictionary_learning_step across RANKS, in two phases around the one all-reduce of the level's
+// [groups, L] window sums (mpcore/matchingpursuit.py::_dictionary_update_by_levels): what the single-process level kernel
+// below does per atom, cut where the other ranks' segments come in.  One workgroup per group (= used atom), events
+// off[g] .. off[g + 1] - 1 of the event arrays (`off`: the level's slice of the offset table, ABSOLUTE positions in the
+// whole event arrays), this rank's segments only.
+//   phase A  residual += the atom's rows (:395-396), acc[g] = fp64 sum over its events of the residual windows (:400-401)
+//   phase B  residual -= new_atoms[g] * ||row_e|| (:408-415), new_atoms = unit_norm(all-reduced acc) (:403-404)
+// An atom none of whose events overlap (overlap[g] == 0 -- almost every atom) needs no staging: its events touch disjoint
+// samples, each sample sees one add (0 + row == row exactly) / one subtract; overlapping events of one atom (same
+// segment, hence same rank) go through `sparse` event after event, as the reference's scatter sums them first.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void dictionary_level_addback_sum_kernel(
+    float *residual, float *sparse, int64_t N, int64_t L, const int64_t *__restrict__ off,
+    const int64_t *__restrict__ ev_batch, const int64_t *__restrict__ ev_lag, const float *__restrict__ ev_rows,
+    const int *__restrict__ overlap, double *__restrict__ acc) {
+    const int64_t g = blockIdx.x;
+    const int tid = threadIdx.x;
+    const int64_t e0 = off[g], e1 = off[g + 1];   // (absolute: the event arrays are the whole tables)
+    const bool apart = overlap == nullptr ? false : overlap[g] == 0;
+    if (apart) {
+        for (int64_t j = tid; j < L; j += 1024) {
+            double a = 0.0;
+            for (int64_t e = e0; e < e1; ++e) {
+                const int64_t t = ev_lag[e] + j;
+                if (t < N) {
+                    const float v = __fadd_rn(residual[ev_batch[e] * N + t], ev_rows[e * L + j]);
+                    residual[ev_batch[e] * N + t] = v;
+                    a += (double)v;
+                }
+            }
+            acc[g * L + j] = a;
+        }
+        return;
+    }
+    for (int64_t e = e0; e < e1; ++e) {   // stage in `sparse`, event after event (they may overlap), then move
+        float *sp = sparse + ev_batch[e] * N + ev_lag[e];
+        const float *row = ev_rows + e * L;
+        const int64_t len = N - ev_lag[e] < L ? N - ev_lag[e] : L;
+        for (int64_t s = tid; s < len; s += 1024) sp[s] = __fadd_rn(sp[s], row[s]);
+        __syncthreads();
+    }
+    for (int64_t e = e0; e < e1; ++e) {
+        const int64_t base = ev_batch[e] * N + ev_lag[e];
+        const int64_t len = N - ev_lag[e] < L ? N - ev_lag[e] : L;
+        for (int64_t s = tid; s < len; s += 1024) {
+            residual[base + s] = __fadd_rn(residual[base + s], sparse[base + s]);
+            sparse[base + s] = 0.0f;  // an overlapping later event then adds an exact zero
+        }
+        __syncthreads();
+    }
+    for (int64_t j = tid; j < L; j += 1024) {
+        double a = 0.0;
+        for (int64_t e = e0; e < e1; ++e) {
+            const int64_t t = ev_lag[e] + j;
+            if (t < N) a += (double)residual[ev_batch[e] * N + t];
+        }
+        acc[g * L + j] = a;
+    }
+}
+
+__global__ __launch_bounds__(1024) void dictionary_level_subtract_kernel(
+    float *residual, float *sparse, int64_t N, int64_t L, const int64_t *__restrict__ off,
+    const int64_t *__restrict__ ev_batch, const int64_t *__restrict__ ev_lag, const float *__restrict__ ev_norm,
+    const int *__restrict__ overlap, const float *__restrict__ new_atoms) {
+    const int64_t g = blockIdx.x;
+    const int tid = threadIdx.x;
+    const int64_t e0 = off[g], e1 = off[g + 1];
+    const float *nw = new_atoms + g * L;
+    const bool apart = overlap == nullptr ? false : overlap[g] == 0;
+    if (apart) {
+        for (int64_t j = tid; j < L; j += 1024) {
+            const float a = nw[j];
+            for (int64_t e = e0; e < e1; ++e) {
+                const int64_t t = ev_lag[e] + j;
+                if (t < N) residual[ev_batch[e] * N + t] = __fsub_rn(residual[ev_batch[e] * N + t], __fmul_rn(a, ev_norm[e]));
+            }
+        }
+        return;
+    }
+    for (int64_t e = e0; e < e1; ++e) {
+        float *sp = sparse + ev_batch[e] * N + ev_lag[e];
+        const float nrm = ev_norm[e];
+        const int64_t len = N - ev_lag[e] < L ? N - ev_lag[e] : L;
+        for (int64_t s = tid; s < len; s += 1024) sp[s] = __fadd_rn(sp[s], __fmul_rn(nw[s], nrm));
+        __syncthreads();
+    }
+    for (int64_t e = e0; e < e1; ++e) {
+        const int64_t base = ev_batch[e] * N + ev_lag[e];
+        const int64_t len = N - ev_lag[e] < L ? N - ev_lag[e] : L;
+        for (int64_t s = tid; s < len; s += 1024) {
+            residual[base + s] = __fsub_rn(residual[base + s], sparse[base + s]);
+            sparse[base + s] = 0.0f;
+        }
+        __syncthreads();
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // The atom-by-atom loop of dictionary_learning_step (modules/matchingpursuit.py:391-415) in ONE launch of ONE
 // workgroup: the loop is sequential by construction (every atom's update reads the residual the earlier
 // atoms left) and touches n_g * L samples per atom, so it is latency-, not bandwidth-bound -- as ~10 small
@@ -2580,6 +2678,32 @@ int mp_gather_sum_groups_f32(const float *x, int64_t B, int64_t N, const int64_t
         return fail(MP_ERR_ARG, "mp_gather_sum_groups_f32: bad arguments%s");
     hipLaunchKernelGGL(gather_sum_groups_kernel, dim3((unsigned)((L + 255) / 256), (unsigned)n_groups), dim3(256), 0,
                        static_cast<hipStream_t>(stream), x, N, batch, lag, offsets, L, out);
+    HIP_TRY(hipGetLastError());
+    return MP_OK;
+}
+
+int mp_dictionary_level_addback_sum_f32(float *residual, float *sparse_zeroed, int64_t B, int64_t N, int64_t L,
+                                        const int64_t *offsets, int64_t n_groups, const int64_t *ev_batch,
+                                        const int64_t *ev_lag, const float *ev_rows, const int *overlap, double *acc,
+                                        void *stream) {
+    if (n_groups == 0) return MP_OK;
+    if (!residual || !sparse_zeroed || !offsets || !acc || B <= 0 || N <= 0 || L <= 0 || n_groups < 0)
+        return fail(MP_ERR_ARG, "mp_dictionary_level_addback_sum_f32: bad arguments%s");
+    hipLaunchKernelGGL(dictionary_level_addback_sum_kernel, dim3((unsigned)n_groups), dim3(1024), 0, static_cast<hipStream_t>(stream),
+                       residual, sparse_zeroed, N, L, offsets, ev_batch, ev_lag, ev_rows, overlap, acc);
+    HIP_TRY(hipGetLastError());
+    return MP_OK;
+}
+
+int mp_dictionary_level_subtract_f32(float *residual, float *sparse_zeroed, int64_t B, int64_t N, int64_t L,
+                                     const int64_t *offsets, int64_t n_groups, const int64_t *ev_batch,
+                                     const int64_t *ev_lag, const float *ev_norm, const int *overlap,
+                                     const float *new_atoms, void *stream) {
+    if (n_groups == 0) return MP_OK;
+    if (!residual || !sparse_zeroed || !offsets || !new_atoms || B <= 0 || N <= 0 || L <= 0 || n_groups < 0)
+        return fail(MP_ERR_ARG, "mp_dictionary_level_subtract_f32: bad arguments%s");
+    hipLaunchKernelGGL(dictionary_level_subtract_kernel, dim3((unsigned)n_groups), dim3(1024), 0, static_cast<hipStream_t>(stream),
+                       residual, sparse_zeroed, N, L, offsets, ev_batch, ev_lag, ev_norm, overlap, new_atoms);
     HIP_TRY(hipGetLastError());
     return MP_OK;
 }

@@ -56,6 +56,7 @@ EXPORTS = (
     "mp_stream_pair_ratio", "mp_init_streams", "mp_audit_read", "mp_dictionary_levels_host",
     "mp_dictionary_update_levels_f32", "mp_persist_stats", "mp_last_schedule", "mp_encode_lazy_f32",
     "mp_coherence_f32", "mp_coherence_workspace_bytes", "mp_lazy_stats", "mp_gather_sum_groups_f32",
+    "mp_dictionary_level_addback_sum_f32", "mp_dictionary_level_subtract_f32",
 )
 
 
@@ -104,6 +105,8 @@ def lib():
         L.mp_scatter_rows_f32.argtypes = [vp, vp, vp, i64, i64, vp, i64, i64, vp]
         L.mp_gather_sum_f32.argtypes = [vp, i64, i64, vp, vp, i64, i64, vp, vp]
         L.mp_gather_sum_groups_f32.argtypes = [vp, i64, i64, vp, vp, vp, i64, i64, vp, vp]
+        L.mp_dictionary_level_addback_sum_f32.argtypes = [vp, vp, i64, i64, i64, vp, i64, vp, vp, vp, vp, vp, vp]
+        L.mp_dictionary_level_subtract_f32.argtypes = [vp, vp, i64, i64, i64, vp, i64, vp, vp, vp, vp, vp, vp]
         L.mp_dictionary_update_f32.argtypes = [vp, vp, i64, i64, vp, i64, i64, vp, vp, i64, vp, vp, vp, vp,
                                                ctypes.c_float, vp, vp]
         L.mp_fft_c2c_f32.argtypes = [vp, vp, ctypes.c_int, i64, ctypes.c_int, vp, vp]
@@ -768,6 +771,34 @@ def gather_sum_groups(x, batch, lag, offsets, L):
             rc = lib().mp_gather_sum_groups_f32(_ptr(x), B, N, _ptr(batch), _ptr(lag), _ptr(offsets), G, L, _ptr(out), _stream(x))
         _check(rc, "mp_gather_sum_groups_f32")
     return out
+
+
+def level_addback_sum(residual, sparse, ev_batch, ev_lag, ev_rows, offsets, overlap, L):
+    """mp_dictionary_level_addback_sum_f32: phase A of one dependency level of the multi-rank dictionary update.
+    `offsets` int64 device [G + 1] (a slice of a longer table), `overlap` int32 device [G] or None -> acc float64 [G, L];
+    `residual` is updated in place, `sparse` ([B, N] zeros) is scratch and zero again on return."""
+    dev = residual.device
+    B, N = residual.shape
+    G = offsets.numel() - 1
+    acc = torch.empty((max(G, 0), L), dtype=torch.float64, device=dev)
+    if G > 0:
+        with torch.cuda.device(dev):
+            rc = lib().mp_dictionary_level_addback_sum_f32(_ptr(residual), _ptr(sparse), B, N, L, _ptr(offsets), G, _ptr(ev_batch),
+                                                           _ptr(ev_lag), _ptr(ev_rows), _ptr(overlap), _ptr(acc), _stream(residual))
+        _check(rc, "mp_dictionary_level_addback_sum_f32")
+    return acc
+
+
+def level_subtract(residual, sparse, ev_batch, ev_lag, ev_norm, offsets, overlap, new_atoms, L):
+    """mp_dictionary_level_subtract_f32: phase B -- residual -= new_atoms[g] * ||row_e|| for every event of every group."""
+    dev = residual.device
+    B, N = residual.shape
+    G = offsets.numel() - 1
+    if G > 0:
+        with torch.cuda.device(dev):
+            rc = lib().mp_dictionary_level_subtract_f32(_ptr(residual), _ptr(sparse), B, N, L, _ptr(offsets), G, _ptr(ev_batch),
+                                                        _ptr(ev_lag), _ptr(ev_norm), _ptr(overlap), _ptr(new_atoms), _stream(residual))
+        _check(rc, "mp_dictionary_level_subtract_f32")
 
 
 def dictionary_levels(offsets, ev_batch, ev_lag, L):
