@@ -139,6 +139,12 @@ int mp_profile_enable(int every);
                                      Replayed from a hipGraph those memset nodes leave WRONG events on this runtime, so 1 is refused
                                      unless the process has MP_ALLOW_WRONG_RESULTS=1 in its environment, like MP_TUNE_LAZY_FORCE   */
 int mp_tune(int key, double value);
+
+/* The form table: every threshold by which MP_PATH_FFT picks its form (one launch / launch per step, which select, sub-
+ * batches, when the lazy screen pays), as doubles in the order of csrc/mpcore.hip::FormTable -- the one place they live;
+ * the host side reads them from here (mpcore/_native.py::form_table, lazy_pays).  Writes up to `capacity` values to `out`
+ * (may be NULL) and returns how many there are. */
+int mp_form_table(double *out, int capacity);
 int mp_profile_read(double *ms, int64_t *count);
 
 /* Device bytes mp_encode_f32 needs in `workspace` for this problem (0 on bad arguments).

@@ -97,9 +97,46 @@ constexpr int KC_MAX = 512;         // atom samples staged in LDS per chunk
 constexpr int MAXCONT = 32;         // FFT path: inexact contender cells per segment per iteration
 constexpr int MP_FLAG_INTERNAL_ONE_STREAM = 1 << 30;  // set by encode_impl: the batch is not split
 constexpr int MP_FLAG_INTERNAL_COHERENCE = 1 << 29;   // set by mp_coherence_f32: |.| screen only
-constexpr int64_t QUARTER_MAX_CELLS = 16384;  // FFT path: segments this small use the quarter-cell select kernel
-constexpr int64_t FUSED_MIN_CELLS = 65536;    // FFT path: from here the whole-cell one-kernel select, with block summaries
-constexpr int64_t PERSIST_MAX_CELLS = 65536;  // FFT path: the persistent form's quarter maxima are kept up to here (16 B per cell)
+// ------------------------------------------------------------------------------------------------
+// THE FORM TABLE: every threshold by which MP_PATH_FFT picks its form for a shape and a load, in one place (mp_form_table
+// hands it to the host side: mpcore/_native.py::lazy_pays reads its numbers from here).  Fitted on one MI355X
+// (scripts/form_sweep.py, small_batches.py, small_batch_forms.py, persist_percu.py, fine_ab.py; the measurements are quoted
+// where each entry is used); tests/test_gpu_parity.py::test_default_form_is_within_reach_of_the_best_forced_form holds
+// the default to the best forced form on six shapes either side of these lines.  Results never depend on the form.
+// ------------------------------------------------------------------------------------------------
+struct FormTable {
+    // cells per segment (64-lag blocks x 32-atom tiles): which select runs between two screens
+    int64_t quarter_max_cells = 16384;    // up to here: the quarter-cell select (sub-cell maxima kept)
+    int64_t fused_min_cells = 65536;      // from here: the whole-cell one-kernel select with block summaries
+    int64_t persist_max_cells = 65536;    // the one-launch form keeps its quarter maxima up to here (16 B per cell)
+    // one launch (persistent) or launch per step, by load = transform points per step = B x ceil(A / 2) x M
+    double persist_points_table = 96e6;        // with the coherence table: one launch up to here ...
+    double persist_points_table_1024 = 100e6;  // ... 1024-point transforms: up to here AND
+    int persist_segments_table_1024 = 64;      // ... at most this many segments (form_sweep, one launch / per step, k seg-it/s: 512 x 256
+                                               //     64 segments 1296 / 981, 128: 1310 / 1431; 2048 x 256: 64: 456 / 434, 128: 448 / 481;
+                                               //     4096 x 256: 16: 177 / 157, 64 = 134 M points: 200 / 238)
+    int sub_batch_min_segments = 48;           // below this many segments the launch-per-step side has one stream: one launch wins
+    double persist_spectra_bytes = 8.5e6;      // without the table: pair spectra that fit the L2s (A / 2 x M x 8 B) ...
+    double persist_points_fit = 200e6;         // ... keep the one-launch form up to here,
+    double persist_points_nofit = 40e6;        // larger dictionaries up to here
+    // short segments (N <= short_ratio x L: an event dirties half of the lags or more): launch per step, quarter select
+    int short_ratio = 4;
+    int short_logm_always = 12;                // at 4096-point transforms at every batch size,
+    int short_logm_small = 11;                 // at 2048-point transforms
+    int short_small_segments = 8;              // ... up to this many segments
+    // sub-batches on forked streams (launch-per-step forms)
+    int sub_batches = 4;
+    // inside the one-launch form
+    int persist_two_per_cu_load = 4;           // tasks per CU in flight up to which two workgroups per CU beat three
+    int persist_fine_num = 11, persist_fine_den = 2;  // finer tasks while 2 x (their number) <= 11 x CUs (~1400 in flight)
+    int persist_select_workers = 48;           // select workers = min(segments, this)
+    // when the lazy screen is worth its table (host side: _native.lazy_pays)
+    int lazy_min_steps = 8, lazy_min_tiles = 4, lazy_always_tiles = 32, lazy_batch_tiles = 384;
+};
+constexpr FormTable FORM{};
+constexpr int64_t QUARTER_MAX_CELLS = FORM.quarter_max_cells;
+constexpr int64_t FUSED_MIN_CELLS = FORM.fused_min_cells;
+constexpr int64_t PERSIST_MAX_CELLS = FORM.persist_max_cells;
 
 __host__ __device__ inline int64_t round_up(int64_t x, int64_t m) { return (x + m - 1) / m * m; }
 
@@ -2352,8 +2389,11 @@ static int encode_impl(const float *signal, int64_t B, int64_t N, const float *d
     if (persist_size) {
         const double pairs = (double)((A + 1) / 2);
         const double points = (double)B * pairs * fp.M;
-        persist_size = (coherence && !conv_model) ? (B < 48 || points <= (fp.logM == 10 ? 40e6 : 96e6))
-                                                  : ((pairs * fp.M * 8.0 <= 8.5e6 && points <= 200e6) || points <= 40e6);
+        persist_size = (coherence && !conv_model)
+                           ? (B < FORM.sub_batch_min_segments ||
+                              (fp.logM == 10 ? (points <= FORM.persist_points_table_1024 && B <= FORM.persist_segments_table_1024)
+                                             : points <= FORM.persist_points_table))
+                           : ((pairs * fp.M * 8.0 <= FORM.persist_spectra_bytes && points <= FORM.persist_points_fit) || points <= FORM.persist_points_nofit);
         // Short segments -- an event dirties half of the segment's lags or more (N <= 4 L: the multiband model's bands are
         // exactly that) -- leave a select nothing to do ahead of its screen and nothing for the lazy screen to skip, and the
         // one-launch form keeps only its 256-thread selects and its hand-offs: launch per step with the quarter select (1024
@@ -2361,7 +2401,7 @@ static int encode_impl(const float *signal, int64_t B, int64_t N, const float *d
         // 1024 atoms, 4096-sample segments, scripts/small_batch_forms.py, k segment-iterations/s one launch / per step: 1
         // segment 22 / 31, 8: 115 / 150, 32: 217 / 279, 64: 223 / 307), at 2048-point transforms up to 8 segments (1024 x 512,
         // 2048 samples: 8: 206 / 233, 16: 359 / 370, 32: 597 / 507), level at 1024 points.
-        if (4 * L >= N && (fp.logM == 12 || (fp.logM == 11 && B <= 8))) {
+        if (FORM.short_ratio * L >= N && (fp.logM == FORM.short_logm_always || (fp.logM == FORM.short_logm_small && B <= FORM.short_small_segments))) {
             persist_size = false;
             short_segments = true;
         }
@@ -2415,10 +2455,10 @@ static int encode_impl(const float *signal, int64_t B, int64_t N, const float *d
     //  0.398 s, three runs each, scripts/c4_full.py)
     if (K > 0 && !(flags & MP_FLAG_NO_OVERLAP) &&
         (((flags & MP_FLAG_OVERLAP) && B >= 8) ||
-         (path == MP_PATH_FFT && B >= 48 && ((int64_t)g.NBLK * g.NAT < 65536 || (coherence && !conv_model))))) {
+         (path == MP_PATH_FFT && B >= FORM.sub_batch_min_segments && ((int64_t)g.NBLK * g.NAT < FORM.fused_min_cells || (coherence && !conv_model))))) {
         const int per_call = (flags >> MP_FLAG_GROUPS_SHIFT) & 7;                  // MP_FLAG_GROUPS(n): this call only
         const int dflt = overlap_groups.load(std::memory_order_relaxed);
-        n_groups = per_call >= 2 && per_call <= MAX_GROUPS ? per_call : (dflt >= 2 && dflt <= MAX_GROUPS ? dflt : 4);
+        n_groups = per_call >= 2 && per_call <= MAX_GROUPS ? per_call : (dflt >= 2 && dflt <= MAX_GROUPS ? dflt : FORM.sub_batches);
     }
     StreamPool *pool = nullptr;
     if (n_groups > 1) {
@@ -2825,6 +2865,22 @@ int mp_lazy_stats(uint64_t *out2 /* [8] */) {
 }
 
 int mp_last_schedule(void) { return last_schedule; }
+
+int mp_form_table(double *out, int capacity) {
+    const double v[] = {(double)FORM.quarter_max_cells, (double)FORM.fused_min_cells, (double)FORM.persist_max_cells,
+                        FORM.persist_points_table, FORM.persist_points_table_1024, (double)FORM.persist_segments_table_1024,
+                        (double)FORM.sub_batch_min_segments,
+                        FORM.persist_spectra_bytes, FORM.persist_points_fit, FORM.persist_points_nofit, (double)FORM.short_ratio,
+                        (double)FORM.short_logm_always, (double)FORM.short_logm_small, (double)FORM.short_small_segments,
+                        (double)FORM.sub_batches, (double)FORM.persist_two_per_cu_load,
+                        (double)FORM.persist_fine_num / FORM.persist_fine_den, (double)FORM.persist_select_workers,
+                        (double)FORM.lazy_min_steps, (double)FORM.lazy_min_tiles, (double)FORM.lazy_always_tiles,
+                        (double)FORM.lazy_batch_tiles};
+    const int n = (int)(sizeof(v) / sizeof(v[0]));
+    if (out)
+        for (int i = 0; i < n && i < capacity; ++i) out[i] = v[i];
+    return n;
+}
 
 int mp_init_streams(void *stream) {
     StreamPool *p = stream_pool(static_cast<hipStream_t>(stream));

@@ -56,7 +56,7 @@ EXPORTS = (
     "mp_stream_pair_ratio", "mp_init_streams", "mp_audit_read", "mp_dictionary_levels_host",
     "mp_dictionary_update_levels_f32", "mp_persist_stats", "mp_last_schedule", "mp_encode_lazy_f32",
     "mp_coherence_f32", "mp_coherence_workspace_bytes", "mp_lazy_stats", "mp_gather_sum_groups_f32",
-    "mp_dictionary_level_addback_sum_f32", "mp_dictionary_level_subtract_f32",
+    "mp_dictionary_level_addback_sum_f32", "mp_dictionary_level_subtract_f32", "mp_form_table",
 )
 
 
@@ -113,6 +113,7 @@ def lib():
         L.mp_dictionary_levels_host.argtypes = [vp, i64, vp, vp, i64, i64, vp, vp, ctypes.POINTER(i64)]
         L.mp_dictionary_update_levels_f32.argtypes = [vp, vp, i64, i64, vp, i64, i64, vp, vp, i64, vp, vp, vp, vp,
                                                       ctypes.c_float, vp, vp, vp, i64, vp]
+        L.mp_form_table.argtypes = [ctypes.POINTER(ctypes.c_double), ctypes.c_int]
         L.mp_init_streams.argtypes = [vp]
         L.mp_audit_read.argtypes = [ctypes.POINTER(ctypes.c_float), ctypes.POINTER(i64),
                                     ctypes.POINTER(ctypes.c_float), ctypes.POINTER(i64)]
@@ -415,6 +416,27 @@ def cached_coherence(dict_unit, build_now=False):
         return None
 
 
+FORM_FIELDS = ("quarter_max_cells", "fused_min_cells", "persist_max_cells", "persist_points_table", "persist_points_table_1024",
+               "persist_segments_table_1024", "sub_batch_min_segments", "persist_spectra_bytes", "persist_points_fit", "persist_points_nofit", "short_ratio",
+               "short_logm_always", "short_logm_small", "short_small_segments", "sub_batches", "persist_two_per_cu_load",
+               "persist_fine_tasks_per_cu", "persist_select_workers", "lazy_min_steps", "lazy_min_tiles", "lazy_always_tiles",
+               "lazy_batch_tiles")
+_form = None
+
+
+def form_table():
+    """mp_form_table: the library's form-selection thresholds (csrc/mpcore.hip::FormTable) as a dict -- the one place the
+    numbers live; lazy_pays below takes its own from here."""
+    global _form
+    if _form is None:
+        buf = (ctypes.c_double * len(FORM_FIELDS))()
+        n = lib().mp_form_table(buf, len(FORM_FIELDS))
+        if n != len(FORM_FIELDS):
+            raise NativeError(f"mp_form_table has {n} entries, this mirror knows {len(FORM_FIELDS)}")
+        _form = dict(zip(FORM_FIELDS, [float(v) for v in buf]))
+    return _form
+
+
 def lazy_pays(batch, n_atoms, n_steps, n_samples=None, atom_samples=None):
     """Is the lazy screen worth asking for (scripts/small_lazy.py, persistent form with / without the table)?  What it saves
     is screen tasks, what it costs is ~1.2 us in every select: it pays where a step has many tile screens to shed -- 512 x 512
@@ -426,17 +448,19 @@ def lazy_pays(batch, n_atoms, n_steps, n_samples=None, atom_samples=None):
         #  operations, 0.13 ms at 1024 x 2048 -- so it is only asked for where the library would look at it:)
         L, N = int(atom_samples), int(n_samples)
         log_m = max(8, (3 * L + 190 - 1).bit_length())        # csrc/mpfft.inc: make_fft_geom -- M = 2^log_m >= 3 L + 190
-        if log_m >= 13 and ((N + 63) // 64) * tiles < 65536:
+        if log_m >= 13 and ((N + 63) // 64) * tiles < form_table()["fused_min_cells"]:
             # transforms of 8192 points and more: no persistent form, and the launch-per-step lazy screen lives in the fused
             # select, which only segments of 65536 cells and more take
             return False
-        if 4 * L >= N:
+        if form_table()["short_ratio"] * L >= N:
             # short segments (an event dirties half of the lags or more): at 4096-point transforms, and at 2048 points up to
             # 8 segments, they run launch per step on the quarter select (csrc/mpcore.hip: encode_impl, short_segments);
             # in the persistent form the table loses too (scripts/small_batch_forms.py, 1024 x 512 atoms, 2048-sample
             # segments, planted events, with / without: 8 segments 206 / 214 k, 32: 552 / 597 k)
             return False
-    return int(n_steps) >= 8 and tiles >= 4 and (tiles >= 32 or int(batch) * tiles >= 384)
+    f = form_table()
+    return int(n_steps) >= f["lazy_min_steps"] and tiles >= f["lazy_min_tiles"] and (
+        tiles >= f["lazy_always_tiles"] or int(batch) * tiles >= f["lazy_batch_tiles"])
 
 
 _tls = __import__("threading").local()   # .lazy: did this thread's last encode() hand the kernel a coherence table?
