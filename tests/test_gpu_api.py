@@ -778,6 +778,69 @@ def test_event_form_of_the_stft_loss_equals_the_dense_form():
     assert (model.atoms.grad - g_dense).abs().max().item() <= 2e-4 * g_dense.abs().max().item()
 
 
+def test_level_phase_kernels_match_the_tensor_statement():
+    """mp_dictionary_level_addback_sum_f32 / mp_dictionary_level_subtract_f32 (one dependency level of the multi-rank
+    dictionary_learning_step, two launches around the all-reduce) against the reference's tensor statement of the same
+    lines (modules/matchingpursuit.py:395-396, 400-401, 408-415: scatter the rows into a zero buffer -- overlapping events
+    of an atom sum there first, event after event --, residual += buffer, window sums, residual -= scattered new atoms):
+    groups with disjoint events (the direct path), groups whose events overlap (the staged path), events cropped at the end
+    of a segment, an empty group; offsets passed as a slice of a longer table.  Bit for bit."""
+    from mpcore import _native as nat
+    rng = np.random.default_rng(9)
+    B, N, L = 3, 700, 96
+    # (group, segment, lag): group 0 disjoint; group 1 overlapping within a segment (lags 40 apart); group 2 empty;
+    # group 3 cropped at the end of a segment and one event elsewhere
+    events = [(0, 0, 10), (0, 1, 300), (0, 2, 500), (1, 0, 200), (1, 0, 240), (1, 0, 260), (1, 2, 50), (3, 1, N - 30), (3, 2, 250)]
+    lead = 4                                  # the level's events start at position 4 of the whole tables
+    off = np.array([0, 2, lead, lead + 3, lead + 7, lead + 7, lead + 9], dtype=np.int64)   # two earlier groups, then this level's four
+    n_ev = lead + len(events)
+    ev_batch = np.zeros(n_ev, dtype=np.int64)
+    ev_lag = np.zeros(n_ev, dtype=np.int64)
+    for i, (_, b, p) in enumerate(events):
+        ev_batch[lead + i], ev_lag[lead + i] = b, p
+    ev_rows = rng.standard_normal((n_ev, L)).astype(np.float32)
+    ev_norm = np.abs(rng.standard_normal(n_ev)).astype(np.float32) + 0.5
+    overlap = np.array([0, 1, 0, 0], dtype=np.int32)
+    res0 = rng.standard_normal((B, N)).astype(np.float32)
+    new_atoms = rng.standard_normal((4, L)).astype(np.float32)
+    # --- the tensor statement, on the host in fp32 / fp64 exactly as the reference's dense tensors do it
+    want = res0.copy()
+    acc_want = np.zeros((4, L), dtype=np.float64)
+    for g in range(4):
+        buf = np.zeros((B, N), dtype=np.float32)
+        for e in range(off[2 + g], off[3 + g]):
+            n_in = min(L, N - ev_lag[e])
+            buf[ev_batch[e], ev_lag[e]:ev_lag[e] + n_in] += ev_rows[e, :n_in]
+        want += buf
+        for e in range(off[2 + g], off[3 + g]):
+            n_in = min(L, N - ev_lag[e])
+            acc_want[g, :n_in] += want[ev_batch[e], ev_lag[e]:ev_lag[e] + n_in].astype(np.float64)
+    after_a = want.copy()
+    for g in range(4):
+        buf = np.zeros((B, N), dtype=np.float32)
+        for e in range(off[2 + g], off[3 + g]):
+            n_in = min(L, N - ev_lag[e])
+            buf[ev_batch[e], ev_lag[e]:ev_lag[e] + n_in] += new_atoms[g, :n_in] * ev_norm[e]
+        want -= buf
+    # --- the kernels
+    residual = torch.from_numpy(res0.copy()).to(DEV)
+    sparse = torch.zeros_like(residual)
+    off_d = torch.from_numpy(off).to(DEV)
+    t = lambda a: torch.from_numpy(a).to(DEV)   # noqa: E731
+    eb, el, er, en, ov = t(ev_batch), t(ev_lag), t(ev_rows), t(ev_norm), t(overlap)
+    acc = nat.level_addback_sum(residual, sparse, eb, el, er, off_d[2:7], ov, L)
+    assert np.array_equal(residual.cpu().numpy(), after_a) and float(sparse.abs().max()) == 0.0
+    assert np.array_equal(acc.cpu().numpy(), acc_want)
+    nat.level_subtract(residual, sparse, eb, el, en, off_d[2:7], ov, t(new_atoms), L)
+    assert np.array_equal(residual.cpu().numpy(), want) and float(sparse.abs().max()) == 0.0
+    # overlap = None: every group through the staged path -- the same result
+    residual2 = torch.from_numpy(res0.copy()).to(DEV)
+    acc2 = nat.level_addback_sum(residual2, sparse, eb, el, er, off_d[2:7], None, L)
+    assert np.array_equal(residual2.cpu().numpy(), after_a) and np.array_equal(acc2.cpu().numpy(), acc_want)
+    nat.level_subtract(residual2, sparse, eb, el, en, off_d[2:7], None, t(new_atoms), L)
+    assert np.array_equal(residual2.cpu().numpy(), want)
+
+
 def test_dictionary_update_levels_are_bit_identical(oracle):
     """The dictionary update spread over the chip (one launch per dependency level, one workgroup per atom:
     mp_dictionary_update_levels_f32) against the one-workgroup loop in its two forms (events of an atom at once /
