@@ -124,10 +124,12 @@ def pmc_valu_fraction(kind, which):
     import glob
     for f in sorted(glob.glob(os.path.join(REPO, "profiles", f"r*_{kind}_summary.json")), reverse=True):
         try:
-            c = json.load(open(f))["sq_counters_dominant_kernel"][which]
+            doc = json.load(open(f))
+            c = (doc.get("sq_counters_dominant_kernel") or doc["sq_counters_fft_screen_kernel"])[which]   # (summarize_profiles / summarize_c4)
             return {"value": round(c["valu_busy_frac_of_simd_cycles"] * c["clock_GHz"] / (PEAK_CLOCK_HZ / 1e9), 4),
                     "valu_busy_frac_of_simd_cycles": c["valu_busy_frac_of_simd_cycles"], "clock_GHz": c["clock_GHz"],
-                    "avg_us_under_counters": c["avg_us"], "from": "profiles/" + os.path.basename(f)}
+                    "avg_us_under_counters": c["avg_us"] if "avg_us" in c else round(c["avg_ms"] * 1e3, 2),
+                    "from": "profiles/" + os.path.basename(f)}
         except (OSError, ValueError, KeyError):
             continue
     return None
