@@ -208,8 +208,10 @@ int mp_encode_conv_f32(const float *signal, int64_t B, int64_t N, const float *a
  *   fm - avg_pool2d(fm, (9, 9), stride 1, padding 4)      over the dense (A, N) map
  * (zero padding, every window divided by 81) and reports the RAW map value there as the gain (:294).
  * The box mean is one sequential fp32 sum in row-major window order, as ATen computes it on the CPU, so
- * selections are bit-identical to the reference's.  The dense map lives in the workspace ([B, A, N] floats:
- * size the batch accordingly) and only the 64-lag blocks an event dirties are recomputed per step.
+ * selections are bit-identical to the reference's.  The dense map lives in the workspace -- B x ceil(N / 64) x ceil(A / 32)
+ * cells of 32 atoms x 64 lags, 8 KiB each, in the matrix core's accumulator order (about 4 B A N bytes: size the batch
+ * accordingly) -- and only the 64-lag blocks an event dirties are recomputed per step (exactly: every value under a 9 x 9
+ * box enters the rule).
  * Arguments as mp_encode_f32; workspace >= mp_lcn_workspace_bytes(...), 256-byte aligned; B <= 65535.
  */
 size_t mp_lcn_workspace_bytes(int64_t B, int64_t N, int64_t A, int64_t L, int K);

@@ -112,6 +112,7 @@ struct FormTable {
     // one launch (persistent) or launch per step, by load = transform points per step = B x ceil(A / 2) x M
     double persist_points_table = 96e6;        // with the coherence table: one launch up to here ...
     double persist_points_table_1024 = 100e6;  // ... 1024-point transforms: up to here AND
+    double persist_points_any_batch_1024 = 20e6;  // ... (small loads: one launch at any batch size up to here)
     int persist_segments_table_1024 = 64;      // ... at most this many segments (form_sweep, one launch / per step, k seg-it/s: 512 x 256
                                                //     64 segments 1296 / 981, 128: 1310 / 1431; 2048 x 256: 64: 456 / 434, 128: 448 / 481;
                                                //     4096 x 256: 16: 177 / 157, 64 = 134 M points: 200 / 238)
@@ -2391,7 +2392,8 @@ static int encode_impl(const float *signal, int64_t B, int64_t N, const float *d
         const double points = (double)B * pairs * fp.M;
         persist_size = (coherence && !conv_model)
                            ? (B < FORM.sub_batch_min_segments ||
-                              (fp.logM == 10 ? (points <= FORM.persist_points_table_1024 && B <= FORM.persist_segments_table_1024)
+                              (fp.logM == 10 ? (points <= FORM.persist_points_any_batch_1024 ||
+                                                (points <= FORM.persist_points_table_1024 && B <= FORM.persist_segments_table_1024))
                                              : points <= FORM.persist_points_table))
                            : ((pairs * fp.M * 8.0 <= FORM.persist_spectra_bytes && points <= FORM.persist_points_fit) || points <= FORM.persist_points_nofit);
         // Short segments -- an event dirties half of the segment's lags or more (N <= 4 L: the multiband model's bands are
@@ -2868,7 +2870,8 @@ int mp_last_schedule(void) { return last_schedule; }
 
 int mp_form_table(double *out, int capacity) {
     const double v[] = {(double)FORM.quarter_max_cells, (double)FORM.fused_min_cells, (double)FORM.persist_max_cells,
-                        FORM.persist_points_table, FORM.persist_points_table_1024, (double)FORM.persist_segments_table_1024,
+                        FORM.persist_points_table, FORM.persist_points_table_1024, FORM.persist_points_any_batch_1024,
+                        (double)FORM.persist_segments_table_1024,
                         (double)FORM.sub_batch_min_segments,
                         FORM.persist_spectra_bytes, FORM.persist_points_fit, FORM.persist_points_nofit, (double)FORM.short_ratio,
                         (double)FORM.short_logm_always, (double)FORM.short_logm_small, (double)FORM.short_small_segments,

@@ -177,6 +177,43 @@ def lds_read_hazards(insts, reads=("ds_read_b64",)):
     return out
 
 
+def vmem_read_hazards(insts):
+    """The same audit for VECTOR-MEMORY loads: a `global_load_*` whose destination is read before an `s_waitcnt vmcnt(n)`
+    has brought the counter down far enough.  csrc/mpfft.inc::screen_task issues the sixteen pair-spectrum loads of a
+    transform as `asm volatile("global_load_dwordx2 ...")` with a scalar base and waits with a separate
+    `asm volatile("s_waitcnt vmcnt(0)")` that carries the sixteen values -- again an order the compiler cannot see.  Loads
+    return in order (vmcnt counts loads; stores have their own counter on gfx950's family only where vscnt exists -- here
+    stores count in vmcnt too, which can only make a wait stronger).  Walks every load's straight-line successors: a use of
+    the destination before a covering wait is a hazard.  -> [(address of the use, its text, address of the load)]"""
+    out = []
+    for i, (a, op, args) in enumerate(insts):
+        if not op.startswith("global_load") or "lds" in op:
+            continue
+        dst = set(_vregs(args.split(",")[0].strip()))
+        later = 0      # vector-memory operations issued after this load
+        for a2, op2, args2 in insts[i + 1:]:
+            if op2.startswith(("s_cbranch", "s_branch", "s_endpgm", "s_setpc", "s_swappc")):
+                break
+            if op2 == "s_waitcnt":
+                m = re.search(r"vmcnt\((\d+)\)", args2)
+                if m and int(m.group(1)) <= later:
+                    break                                    # this load has returned
+                continue
+            ops2 = [o.strip() for o in args2.split(",")] if args2 else []
+            used = set()
+            for o in _sources(op2, ops2):
+                used.update(_vregs(o))
+            if dst & used:
+                out.append((a2, f"{op2} {args2}", a))
+                break
+            if op2.startswith(("global_", "buffer_", "flat_", "scratch_")):
+                later += 1
+            wr = set(_vregs(ops2[0])) if ops2 and not op2.startswith(("ds_write", "global_store", "buffer_store", "scratch_store")) else set()
+            if dst & wr:
+                break
+    return out
+
+
 if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "--hazards":
         res = kernel_resources()
@@ -188,6 +225,10 @@ if __name__ == "__main__":
             bad += len(h)
             for a, text, pa in h[:5]:
                 print(f"{name[:60]}: {a:#x} {text[:70]} uses the destination of the LDS read at {pa:#x}")
+            hv = vmem_read_hazards(insts)
+            bad += len(hv)
+            for a, text, pa in hv[:5]:
+                print(f"{name[:60]}: {a:#x} {text[:70]} uses the destination of the global load at {pa:#x}")
         print(f"{len(res)} kernels, {n_reads} ds_read_b64, {bad} hazards")
         sys.exit(1 if bad else 0)
     if len(sys.argv) > 1 and sys.argv[1] == "--pair-loops":

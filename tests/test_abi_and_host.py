@@ -202,6 +202,29 @@ def test_lds_reads_of_the_transform_are_consumed_behind_their_wait():
     assert reads > 1000   # (the transform is inlined into ~20 kernels, 56+ reads each)
 
 
+def test_global_loads_are_consumed_behind_their_wait():
+    """Round 4: screen_task's sixteen pair-spectrum loads per transform are `asm volatile("global_load_dwordx2 v, v_off,
+    s[base]")` (a scalar base per element: no 64-bit vector address arithmetic) waited for by a separate
+    `asm volatile("s_waitcnt vmcnt(0)")` that carries the sixteen values.  The same audit as for the LDS reads, over
+    every global load of every kernel in the built code object (scripts/kernel_resources.py::vmem_read_hazards): none is
+    read before a vmcnt wait that covers it."""
+    kr = _kernel_resources_module()
+    bad = [(0, "global_load_dwordx2", "v[4:5], v1, s[2:3]"), (8, "v_pk_mul_f32", "v[6:7], v[4:5], v[8:9]"), (16, "s_waitcnt", "vmcnt(0)")]
+    good = [(0, "global_load_dwordx2", "v[4:5], v1, s[2:3]"), (8, "s_waitcnt", "vmcnt(0)"), (12, "v_pk_mul_f32", "v[6:7], v[4:5], v[8:9]")]
+    part = [(0, "global_load_dwordx2", "v[4:5], v1, s[2:3]"), (8, "global_load_dwordx2", "v[6:7], v1, s[4:5]"), (16, "s_waitcnt", "vmcnt(1)"),
+            (20, "v_pk_add_f32", "v[10:11], v[4:5], v[4:5]"), (28, "v_pk_add_f32", "v[12:13], v[6:7], v[6:7]")]
+    other = [(0, "global_load_dwordx2", "v[4:5], v1, s[2:3]"), (8, "s_waitcnt", "lgkmcnt(0)"), (12, "v_pk_mul_f32", "v[6:7], v[4:5], v[8:9]")]
+    assert len(kr.vmem_read_hazards(bad)) == 1 and kr.vmem_read_hazards(good) == []
+    assert [h[0] for h in kr.vmem_read_hazards(part)] == [28] and len(kr.vmem_read_hazards(other)) == 1
+    loads = asm_form = 0
+    for name in kr.kernel_resources():
+        insts = kr.kernel_instructions(name + ">:")
+        loads += sum(op.startswith("global_load") for _, op, _ in insts)
+        asm_form += sum(op == "global_load_dwordx2" and re.search(r"s\[\d+:\d+\]", args or "") is not None for _, op, args in insts)
+        assert kr.vmem_read_hazards(insts) == [], name
+    assert loads > 1000 and asm_form >= 16 * 9   # (sixteen scalar-base loads in each of the register screen kernels at least)
+
+
 def test_bench_prices_the_screen_with_the_instruction_counts_of_the_built_code():
     """bench.py's VALU roofline multiplies transforms by the VALU instructions one 16-point thread-transform costs; that
     number is READ from the built code object (the pair loop of the kernel that ran: scripts/kernel_resources.py::
