@@ -214,6 +214,48 @@ def vmem_read_hazards(insts):
     return out
 
 
+def _sregs(operand):
+    m = re.fullmatch(r"s(\d+)", operand)
+    if m:
+        return [int(m.group(1))]
+    m = re.fullmatch(r"s\[(\d+):(\d+)\]", operand)
+    if m:
+        return list(range(int(m.group(1)), int(m.group(2)) + 1))
+    return []
+
+
+VALU_SGPR_WRITERS = ("v_readlane_b32", "v_readfirstlane_b32")
+
+
+def sgpr_base_hazards(insts, wait_states=5):
+    """A vector-memory instruction whose SCALAR base was written by a VALU instruction (v_readlane / v_readfirstlane: SGPR
+    spill reloads, hand-made uniform values) fewer than `wait_states` instructions earlier.  gfx9 needs five wait states
+    between a VALU write of an SGPR and a VMEM read of it; the compiler's hazard recognizer inserts them for its own
+    memory instructions but does not look inside inline asm -- csrc/mpfft.inc's `global_load_dwordx2 v, v_off, s[base]`.
+    (Every instruction counts as one wait state here, s_nop n as n + 1: conservative in the right direction only for
+    s_nop; a VALU / SALU instruction in between is at least one.)  -> [(address of the load, its text, address of the write)]"""
+    out = []
+    for i, (a, op, args) in enumerate(insts):
+        if not op.startswith(("global_load", "global_store", "global_atomic")) or not args:
+            continue
+        ops = [o.strip() for o in args.split(",")]
+        base = set()
+        for o in ops:
+            base.update(_sregs(o.split(" ")[0]))
+        if not base:
+            continue
+        states = 0
+        for a2, op2, args2 in reversed(insts[max(0, i - 12):i]):
+            if op2 in VALU_SGPR_WRITERS and args2:
+                if base & set(_sregs(args2.split(",")[0].strip())) and states < wait_states:
+                    out.append((a, f"{op} {args}", a2))
+                    break
+            states += (int(args2.strip(), 0) + 1) if op2 == "s_nop" and args2 else 1
+            if states >= wait_states:
+                break
+    return out
+
+
 if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "--hazards":
         res = kernel_resources()
@@ -225,7 +267,7 @@ if __name__ == "__main__":
             bad += len(h)
             for a, text, pa in h[:5]:
                 print(f"{name[:60]}: {a:#x} {text[:70]} uses the destination of the LDS read at {pa:#x}")
-            hv = vmem_read_hazards(insts)
+            hv = vmem_read_hazards(insts) + sgpr_base_hazards(insts)
             bad += len(hv)
             for a, text, pa in hv[:5]:
                 print(f"{name[:60]}: {a:#x} {text[:70]} uses the destination of the global load at {pa:#x}")

@@ -225,6 +225,23 @@ def test_global_loads_are_consumed_behind_their_wait():
     assert loads > 1000 and asm_form >= 16 * 9   # (sixteen scalar-base loads in each of the register screen kernels at least)
 
 
+def test_scalar_bases_of_memory_instructions_are_not_fresh_from_the_valu():
+    """gfx9 wants five wait states between a VALU write of an SGPR (v_readlane: an SGPR spilled into a VGPR lane comes back;
+    v_readfirstlane) and a memory instruction that reads it as its base; the compiler pads its own memory instructions but
+    does not look inside inline asm.  Round 4 met exactly that: the split screen's hoisted window-spectrum bases were
+    spilled into VGPR lanes and read back right in front of the hand-written loads, which went out with stale bases.
+    The audit (scripts/kernel_resources.py::sgpr_base_hazards) walks every kernel of the built code object."""
+    kr = _kernel_resources_module()
+    bad = [(0, "v_readlane_b32", "s10, v126, 15"), (4, "v_readlane_b32", "s11, v126, 16"), (8, "global_load_dwordx2", "v[4:5], v121, s[10:11]")]
+    padded = [(0, "v_readlane_b32", "s10, v126, 15"), (4, "v_readlane_b32", "s11, v126, 16"), (8, "s_nop", "4"),
+              (12, "global_load_dwordx2", "v[4:5], v121, s[10:11]")]
+    salu = [(0, "v_readlane_b32", "s8, v126, 15"), (4, "s_add_u32", "s10, s8, 0x2000"), (8, "s_addc_u32", "s11, s9, 0"),
+            (12, "global_load_dwordx2", "v[4:5], v121, s[10:11]")]
+    assert len(kr.sgpr_base_hazards(bad)) == 1 and kr.sgpr_base_hazards(padded) == [] and kr.sgpr_base_hazards(salu) == []
+    for name in kr.kernel_resources():
+        assert kr.sgpr_base_hazards(kr.kernel_instructions(name + ">:")) == [], name
+
+
 def test_bench_prices_the_screen_with_the_instruction_counts_of_the_built_code():
     """bench.py's VALU roofline multiplies transforms by the VALU instructions one 16-point thread-transform costs; that
     number is READ from the built code object (the pair loop of the kernel that ran: scripts/kernel_resources.py::
