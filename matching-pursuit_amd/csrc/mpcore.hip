@@ -907,27 +907,36 @@ __global__ __launch_bounds__(256) void lcn_keys_kernel(const float *__restrict__
         const float *col = &tile[w * 8][lane];
 #pragma unroll
         for (int rr = 0; rr < 16; ++rr) {
+            // the row's nine values as register PAIRS (two neighbouring lags per LDS read: ds_read2_b32 fills a pair), so that
+            // the packed additions take a value straight from the half of the pair it sits in (op_sel) -- built from single
+            // registers every packed add cost a v_mov and a hazard s_nop first: 84 + 82 of the loop's 890 instructions
+            f32x2 w[5];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) w[q] = f32x2{col[rr * (LCN_W + 1) + 2 * q], col[rr * (LCN_W + 1) + 2 * q + 1]};
+            w[4] = f32x2{col[rr * (LCN_W + 1) + 8], 0.0f};
             float v[9];
 #pragma unroll
-            for (int dt = 0; dt < 9; ++dt) v[dt] = col[rr * (LCN_W + 1) + dt];
+            for (int dt = 0; dt < 9; ++dt) v[dt] = (dt & 1) ? w[dt >> 1].y : w[dt >> 1].x;
             if (rr >= 4 && rr < 12) centre[rr - 4] = v[4];
+            // lags outer, sums inner: consecutive packed additions then belong to DIFFERENT sums (a packed result needs a
+            // wait state before a dependent instruction may read it: four interleaved chains hide it, one chain at a time
+            // had an s_nop behind every addition)
 #pragma unroll
-            for (int p = 0; p < 4; ++p) {
-                const int lo = 2 * p, hi = 2 * p + 1;           // outputs (rows of the cell) of this pair
-                const bool in_lo = rr >= lo && rr <= lo + 8, in_hi = rr >= hi && rr <= hi + 8;
-                if (in_lo && in_hi) {
+            for (int dt = 0; dt < 9; ++dt) {
 #pragma unroll
-                    for (int dt = 0; dt < 9; ++dt) {
-                        f32x2 src;
-                        src.x = v[dt];
-                        asm("v_pk_add_f32 %0, %1, %2 op_sel_hi:[1,0]" : "=v"(sum[p]) : "v"(sum[p]), "v"(src));
+                for (int p = 0; p < 4; ++p) {
+                    const int lo = 2 * p, hi = 2 * p + 1;           // outputs (rows of the cell) of this pair of sums
+                    const bool in_lo = rr >= lo && rr <= lo + 8, in_hi = rr >= hi && rr <= hi + 8;
+                    if (in_lo && in_hi) {
+                        if (dt & 1)   // both sums += the HIGH half of the register pair
+                            asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,1]" : "=v"(sum[p]) : "v"(sum[p]), "v"(w[dt >> 1]));
+                        else          // both sums += the LOW half
+                            asm("v_pk_add_f32 %0, %1, %2 op_sel_hi:[1,0]" : "=v"(sum[p]) : "v"(sum[p]), "v"(w[dt >> 1]));
+                    } else if (in_lo) {
+                        sum[p].x = __fadd_rn(sum[p].x, v[dt]);
+                    } else if (in_hi) {
+                        sum[p].y = __fadd_rn(sum[p].y, v[dt]);
                     }
-                } else if (in_lo) {
-#pragma unroll
-                    for (int dt = 0; dt < 9; ++dt) sum[p].x = __fadd_rn(sum[p].x, v[dt]);
-                } else if (in_hi) {
-#pragma unroll
-                    for (int dt = 0; dt < 9; ++dt) sum[p].y = __fadd_rn(sum[p].y, v[dt]);
                 }
             }
         }
