@@ -136,12 +136,70 @@ class _ConvModelEventsFn(torch.autograd.Function):
         return lam, _sum_rows_by_atom(rows, a_idx, A), None, None
 
 
+_stft_windows = {}
+
+
 def reference_stft(x, ws=2048, step=256):
     """modules/stft.py:7-36 with pad=True, as mp.py:71-73 calls it: [B, C, T] -> [B, C, T // step, ws // 2 + 1]."""
     frames = x.shape[-1] // step
     x = torch.nn.functional.pad(x, (0, ws)).unfold(-1, ws, step)
-    x = x * torch.hann_window(ws, device=x.device)[None, None, :]
+    key = (ws, str(x.device))
+    win = _stft_windows.get(key)
+    if win is None:
+        win = _stft_windows[key] = torch.hann_window(ws, device=x.device)
+    x = x * win[None, None, :]
     return torch.abs(torch.fft.rfft(x, norm="ortho"))[:, :, :frames, :]
+
+
+_loss_consts = {}
+
+
+def _loss_constants(ws, slots, L, B, dev):
+    """Tensors of the event-form loss that depend on shapes only (the Hann window, index ramps): built once per
+    (window, slots, atom length, batch, device) -- rebuilt per call they were ten small launches of a host-bound step."""
+    key = (ws, slots, L, B, str(dev))
+    c = _loss_consts.get(key)
+    if c is None:
+        if len(_loss_consts) > 16:
+            _loss_consts.clear()
+        c = _loss_consts[key] = dict(hann=torch.hann_window(ws, device=dev), s=torch.arange(slots, device=dev),
+                                     n=torch.arange(ws, device=dev), j=torch.arange(L, device=dev),
+                                     b=torch.arange(B, device=dev))
+    return c
+
+
+class _FramePiecesFn(torch.autograd.Function):
+    """pieces[b, k, s, n] = hann[n] * windows[b, k, (f0 + s) step + n - t]  (zero outside the event's window and beyond the
+    last frame): the frames an event's support touches, windowed.  The backward GATHERS -- every window sample sits in
+    at most ws / step + 1 frames, summed in a fixed order -- where autograd's backward of the forward's gather is a
+    scatter-add of B K S ws atomics (5.7 M at the config-5 shape: 0.38 ms of a 2.7 ms train step, non-deterministic)."""
+
+    @staticmethod
+    def forward(ctx, windows, t_idx, f0, step, frames, c):
+        B, K, L = windows.shape
+        S, ws = c["s"].numel(), c["n"].numel()
+        f = f0[:, :, None] + c["s"][None, None, :]                                          # [B, K, S]
+        rel = f[..., None] * step + c["n"] - t_idx[:, :, None, None]                        # index into the window
+        inside = (rel >= 0) & (rel < L) & (f[..., None] < frames)
+        pieces = torch.where(inside, torch.gather(windows[:, :, None, :].expand(B, K, S, L), 3, rel.clamp(0, L - 1)),
+                             torch.zeros((), device=windows.device)) * c["hann"]
+        ctx.save_for_backward(t_idx, f0)
+        ctx.meta = (step, frames, c, L)
+        return pieces
+
+    @staticmethod
+    def backward(ctx, gp):
+        t_idx, f0 = ctx.saved_tensors
+        step, frames, c, L = ctx.meta
+        B, K, S, ws = gp.shape
+        f = f0[:, :, None] + c["s"][None, None, :]                                          # [B, K, S]
+        # sample j of the window is entry n = j + t - f step of frame f
+        n_idx = c["j"][None, None, :, None] + (t_idx[:, :, None] - f * step)[:, :, None, :]  # [B, K, L, S]
+        ok = (n_idx >= 0) & (n_idx < ws) & (f < frames)[:, :, None, :]
+        flat = c["s"][None, None, None, :] * ws + n_idx.clamp(0, ws - 1)
+        vals = torch.gather((gp * c["hann"]).reshape(B, K, S * ws), 2, flat.reshape(B, K, L * S)).reshape(B, K, L, S)
+        gw = torch.where(ok, vals, torch.zeros((), device=gp.device)).sum(-1)
+        return gw, None, None, None, None, None
 
 
 def stft_iterative_loss(model, target, ws=2048, step=256):
@@ -162,16 +220,13 @@ def stft_iterative_loss(model, target, ws=2048, step=256):
     B, K, L = windows.shape
     frames = n // step
     slots = (ws + L) // step + 1
+    c = _loss_constants(ws, slots, L, B, dev)
     f0 = torch.clamp(torch.div(t_idx - ws, step, rounding_mode="floor") + 1, min=0)       # first frame touched
-    f = f0[:, :, None] + torch.arange(slots, device=dev)[None, None, :]                   # [B, K, S]
-    g = f[..., None] * step + torch.arange(ws, device=dev)                                # sample of frame entry
-    rel = g - t_idx[:, :, None, None]                                                     # index into the window
-    inside = (rel >= 0) & (rel < L) & (f[..., None] < frames)
-    pieces = torch.where(inside, torch.gather(windows[:, :, None, :].expand(B, K, slots, L), 3,
-                                              rel.clamp(0, L - 1)), torch.zeros((), device=dev))
-    mags = torch.abs(torch.fft.rfft(pieces * torch.hann_window(ws, device=dev), norm="ortho"))  # [B, K, S, bins]
+    pieces = _FramePiecesFn.apply(windows, t_idx, f0, step, frames, c)                    # [B, K, S, ws], windowed
+    mags = torch.abs(torch.fft.rfft(pieces, norm="ortho"))                                # [B, K, S, bins]
     bins = ws // 2 + 1
-    flat = (torch.arange(B, device=dev)[:, None, None] * frames + f.clamp(max=frames - 1)).reshape(-1)
+    f = f0[:, :, None] + c["s"][None, None, :]
+    flat = (c["b"][:, None, None] * frames + f.clamp(max=frames - 1)).reshape(-1)
     summed = torch.zeros(B * frames, bins, device=dev).index_add_(0, flat, mags.reshape(-1, bins))
     t_spec = reference_stft(x[:, None, :], ws, step).reshape(B * frames, bins)
     return (t_spec - summed).abs().sum() - t_spec.abs().sum()
