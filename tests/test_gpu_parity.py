@@ -941,6 +941,12 @@ def test_default_form_is_within_reach_of_the_best_forced_form():
             k2 = keep & ~torch.isnan(out[2]).any(dim=1)
             assert all(torch.equal(p[k2], q[k2]) for p, q in zip(out, out_def)), (A, L, B, name)
         best_name = min(times, key=times.get)
+        for _ in range(2):   # (a clock, on a box other tenants share: before calling the table wrong, measure both sides again)
+            if t_def <= 1.08 * times[best_name]:
+                break
+            t_def = min(t_def, rate(0)[0])
+            times[best_name] = min(times[best_name], rate(dict(forms)[best_name])[0])
+            best_name = min(times, key=times.get)
         report.append((A, L, B, "table" if co is not False else "no table", sched, round(times[best_name] / t_def, 3), best_name))
         assert t_def <= 1.08 * times[best_name], (A, L, B, sched, t_def, times)
     print("default / best forced form (A, L, B, table, schedule taken, best time / default time, best form):", report)
