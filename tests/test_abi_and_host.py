@@ -256,6 +256,20 @@ def test_bench_prices_the_screen_with_the_instruction_counts_of_the_built_code()
         assert got["valu"] == want, (kind, lg, got)
         assert got["barriers"] in (4, 6) and got["packed"] > 0.75 * got["valu"]
     assert bench.valu_per_thread_transform("persistent", 11)[1] == "code object"
+    # ... and `roofline.frac` is priced by the ALGORITHM's count (bench.py::min_valu_per_thread_transform): the model's numbers,
+    # its relation to the built loops (never above them; the butterflies' packed additions -- which no implementation of this
+    # factorisation can avoid -- are exactly the model's: idft16 = 64, idft8 pair = 48, radix-2 / radix-4 tail = 16 / 32)
+    assert [bench.min_valu_per_thread_transform(lg)[0] for lg in (10, 11, 12, 13, 14)] == [294, 324, 348, 380, 404]
+    for (kind, lg), adds in ((("screen", 11), 48 + 64 + 64), (("persistent", 11), 48 + 64 + 64), (("screen", 13), 64 * 3 + 16)):
+        insts = kr.kernel_instructions(kr.SCREEN_KERNELS[(kind, lg)])
+        loop = max(((lo, hi) for lo, hi in kr.loops(insts)
+                    if sum(op.startswith("global_load") for _, op, _ in insts[lo:hi + 1]) == 16
+                    and not any("mfma" in op for _, op, _ in insts[lo:hi + 1])), key=lambda r: r[1] - r[0])
+        body = insts[loop[0]:loop[1] + 1]
+        assert sum(op == "v_pk_add_f32" for _, op, _ in body) == adds, (kind, lg)
+        assert bench.min_valu_per_thread_transform(lg)[0] < kr.screen_pair_loop(kind, lg)["valu"]
+    f = bench.algorithmic_fractions(300000, 11, 1e-3, 401)
+    assert f["frac"] < f["frac_issue"] and abs(f["frac"] / f["frac_issue"] - 324 / 401) < 5e-3 and f["frac_flops"] < f["frac"]
 
 
 def test_dictionary_levels_host_helper_matches_brute_force():
