@@ -680,13 +680,23 @@ def test_streaming_encode_carries_the_residual(oracle, order):
     the earlier windows left -- checked window by window against the oracle run in the same order -- and
     decode(events) + residual gives the audio back."""
     from mpcore import streaming
-    A, L, window, hop, K, B, T = 24, 128, 2048, 1024, 6, 2, 5000
+    _streaming_walk(oracle, order, hop=1024, want_windows=4)
+    _streaming_walk(oracle, order, hop=1536, want_windows=3)    # (windows of equal parity with a gap between them: the strided view)
+    _streaming_walk(oracle, order, hop=2048, want_windows=3)    # (no overlap at all)
+    with pytest.raises(ValueError):
+        streaming.encode_streaming(torch.zeros(1, 100, device=DEV), torch.rand(4, 16, device=DEV), 64, 16, 2,
+                                   order="even_odd")
+
+
+def _streaming_walk(oracle, order, hop, want_windows):
+    from mpcore import streaming
+    A, L, window, K, B, T = 24, 128, 2048, 6, 2, 5000
     d = synth.make_dictionary(A, L, seed=77)
     audio = synth.make_segments(B, T, d, n_events=30, seed=78)
     code = streaming.encode_streaming(torch.from_numpy(audio).to(DEV), torch.from_numpy(d).to(DEV), window, hop, K,
                                       order=order)
     W = streaming.n_windows(T, window, hop)
-    assert code.atom.shape == (B, W, K) and code.residual.shape == (B, T) and W == 4
+    assert code.atom.shape == (B, W, K) and code.residual.shape == (B, T) and W == want_windows
     # the same walk on the CPU oracle
     du = oracle.unit_norm(d)
     padded = (W - 1) * hop + window
@@ -705,9 +715,6 @@ def test_streaming_encode_carries_the_residual(oracle, order):
     scale = np.abs(audio).max()
     assert np.abs(rec.cpu().numpy() + code.residual.cpu().numpy() - audio).max() <= 1e-5 * scale
     assert np.linalg.norm(code.residual.cpu().numpy()) < np.linalg.norm(audio)
-    with pytest.raises(ValueError):
-        streaming.encode_streaming(torch.zeros(1, 100, device=DEV), torch.rand(4, 16, device=DEV), 64, 16, 2,
-                                   order="even_odd")
 
 
 def test_encode_plan_replays_a_captured_graph(oracle):
