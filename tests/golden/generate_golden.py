@@ -339,6 +339,9 @@ LCN_CASES = [
     ("lcn_24x100_n1000_b2_k10", 24, 100, 1000, 2, 10, 8, 707),
     ("lcn_64x128_n4096_b3_k12", 64, 128, 4096, 3, 12, 12, 808),
     ("lcn_7x33_n300_b2_k6", 7, 33, 300, 2, 6, 4, 909),   # fewer atoms than the 9-row box
+    # the headline dictionary and segment length (16 atom tiles x 512 lag blocks: every kind of cell-to-cell halo of the
+    # native schedule's map); the 1 MB dictionary is regenerated from its seed, checksums stored (round 4)
+    ("lcn_c2shape_512x512_n32768_b2_k8", 512, 512, 32768, 2, 8, 24, 1808),
 ]
 
 
@@ -370,8 +373,10 @@ def run_encode_lcn(mp, signal, d, n_steps):
                 residual=residual.numpy()[:, 0, :].copy())
 
 
-def lcn_fixtures(mp, norm):
+def lcn_fixtures(mp, norm, only=None):
     for name, A, L, N, B, K, n_ev, seed in LCN_CASES:
+        if only is not None and name != only:
+            continue
         d = synth.make_dictionary(A, L, seed=seed)
         x = synth.make_segments(B, N, d, n_events=n_ev, seed=seed)
         dt = torch.from_numpy(d)
@@ -380,9 +385,19 @@ def lcn_fixtures(mp, norm):
             d_new = mp.dictionary_learning_step(torch.from_numpy(x)[:, None, :], torch.from_numpy(d.copy()),
                                                 n_steps=K, local_constrast_norm=True)
         gap = (out["top2"][..., 0] - out["top2"][..., 1]) / np.abs(out["top2"][..., 0])
-        np.savez_compressed(os.path.join(HERE, f"encode_{name}.npz"), signal=x, d_raw=d,
-                            d_unit=norm.unit_norm(dt).numpy().astype(np.float32), d_new=d_new.numpy(),
-                            seed=np.int64(seed), **out)
+        du = norm.unit_norm(dt).numpy().astype(np.float32)
+        if A * L > 65536:    # a large dictionary: from its seed, with checksums (and the learning step's result by checksum + rows)
+            dn = d_new.numpy()
+            np.savez_compressed(os.path.join(HERE, f"encode_{name}.npz"), signal=x, seed=np.int64(seed),
+                                shape=np.array([A, L, N, B, K], dtype=np.int64),
+                                d_unit_sum=np.float64(du.astype(np.float64).sum()),
+                                d_unit_abs_sum=np.float64(np.abs(du.astype(np.float64)).sum()), d_unit_head=du[:2],
+                                d_new_sum=np.float64(dn.astype(np.float64).sum()),
+                                d_new_abs_sum=np.float64(np.abs(dn.astype(np.float64)).sum()),
+                                d_new_rows=dn[np.unique(out["atom"])[:8]], d_new_row_index=np.unique(out["atom"])[:8], **out)
+        else:
+            np.savez_compressed(os.path.join(HERE, f"encode_{name}.npz"), signal=x, d_raw=d, d_unit=du, d_new=d_new.numpy(),
+                                seed=np.int64(seed), **out)
         print("  lcn", name, "min relative top-2 gap of the normalised map", float(gap.min()))
 
 
@@ -706,11 +721,11 @@ if __name__ == "__main__":
         torch.manual_seed(0)
         torch.set_num_threads(8)
         key_point_gradients(load_reference()[0])
-    elif len(sys.argv) > 1 and sys.argv[1] == "lcn":  # only the local-contrast-norm fixtures
+    elif len(sys.argv) > 1 and sys.argv[1] == "lcn":  # only the local-contrast-norm fixtures (all, or the one named)
         torch.manual_seed(0)
         torch.set_num_threads(8)
         _mp, _conv, _norm, _stft, _ns = load_reference()
-        lcn_fixtures(_mp, _norm)
+        lcn_fixtures(_mp, _norm, only=sys.argv[2] if len(sys.argv) > 2 else None)
     elif len(sys.argv) > 2 and sys.argv[1] == "encode":  # one case of ENCODE_CASES
         main(only=sys.argv[2])
     elif len(sys.argv) > 1 and sys.argv[1] == "c4":  # only the configs[3]-shape encode (minutes of CPU)

@@ -270,6 +270,33 @@ def test_local_contrast_norm_matches_reference_golden(oracle, golden_dir, name):
     assert np.array_equal(gain, want["gain"]) and np.array_equal(residual, want["residual"])
 
 
+def test_local_contrast_norm_at_the_headline_shape_matches_reference_golden(oracle, golden_dir):
+    """mp_encode_lcn_f32 at the headline dictionary and segment length against the REFERENCE's own
+    sparse_code(local_contrast_norm=True) run at that size (tests/golden/generate_golden.py lcn: 512 x 512, 2 x 32768
+    samples, 8 steps, smallest relative top-2 gap of the normalised map 1.5e-3), and bitwise against the oracle; and
+    dictionary_learning_step(local_constrast_norm=True) against the reference's new dictionary (checksums + the rows of
+    the first atoms used)."""
+    import modules.matchingpursuit as mp
+    z = np.load(os.path.join(golden_dir, "encode_lcn_c2shape_512x512_n32768_b2_k8.npz"))
+    A, L, N, B, K = [int(v) for v in z["shape"]]
+    d_raw = synth.make_dictionary(A, L, seed=int(z["seed"]))
+    du = nat.unit_norm(torch.from_numpy(d_raw).to(DEV))
+    du_host = du.cpu().numpy()
+    assert abs(du_host.astype(np.float64).sum() - float(z["d_unit_sum"])) <= 1e-4
+    assert np.abs(du_host[:2] - z["d_unit_head"]).max() <= 2e-7
+    atom, lag, gain, residual = [t.cpu().numpy() for t in nat.encode_lcn(torch.from_numpy(z["signal"]).to(DEV), du, K)]
+    assert np.array_equal(atom, z["atom"]) and np.array_equal(lag, z["lag"])
+    assert np.abs(gain - z["gain"]).max() <= REL * np.abs(z["gain"]).max()
+    assert np.abs(residual - z["residual"]).max() <= REL * np.abs(z["signal"]).max()
+    want = oracle.encode_lcn(z["signal"], du_host, K)
+    assert np.array_equal(gain, want["gain"]) and np.array_equal(residual, want["residual"])
+    d_new = mp.dictionary_learning_step(torch.from_numpy(z["signal"]).to(DEV)[:, None, :], torch.from_numpy(d_raw).to(DEV),
+                                        n_steps=K, local_constrast_norm=True).cpu().numpy()
+    assert np.abs(d_new[z["d_new_row_index"]] - z["d_new_rows"]).max() <= 2e-6
+    assert abs(d_new.astype(np.float64).sum() - float(z["d_new_sum"])) <= 1e-3
+    assert abs(np.abs(d_new.astype(np.float64)).sum() - float(z["d_new_abs_sum"])) <= 1e-7 * float(z["d_new_abs_sum"])
+
+
 @pytest.mark.parametrize("shape", ["ragged", "mid", "tiny", "atom_longer_than_segment", "k_chunks", "many_atoms",
                                    "split_batch"])
 def test_local_contrast_norm_bitwise_vs_oracle(oracle, shape):

@@ -140,6 +140,22 @@ def test_oracle_local_contrast_norm_matches_reference(oracle, golden_dir, name):
         assert not (np.array_equal(plain["atom"], out["atom"]) and np.array_equal(plain["lag"], out["lag"]))
 
 
+def test_oracle_local_contrast_norm_at_the_headline_shape(oracle, golden_dir):
+    """The reference's sparse_code(local_contrast_norm=True) on the headline dictionary and segment length (512 x 512,
+    2 x 32768 samples, 8 steps; dictionary regenerated from its seed and checked against the fixture's checksums):
+    16 atom tiles x 512 lag blocks -- every kind of cell-to-cell halo the native schedule's cell-order map has."""
+    z = np.load(os.path.join(golden_dir, "encode_lcn_c2shape_512x512_n32768_b2_k8.npz"))
+    A, L, N, B, K = [int(v) for v in z["shape"]]
+    du = oracle.unit_norm(synth.make_dictionary(A, L, seed=int(z["seed"])))
+    assert abs(du.astype(np.float64).sum() - float(z["d_unit_sum"])) <= 1e-4 and np.abs(du[:2] - z["d_unit_head"]).max() <= 2e-7
+    gap = (z["top2"][..., 0] - z["top2"][..., 1]) / np.abs(z["top2"][..., 0])
+    assert gap.min() >= 1e-4
+    out = oracle.encode_lcn(z["signal"], du, K)
+    assert np.array_equal(out["atom"], z["atom"]) and np.array_equal(out["lag"], z["lag"])
+    assert np.abs(out["gain"] - z["gain"]).max() <= REL * np.abs(z["gain"]).max()
+    assert np.abs(out["residual"] - z["residual"]).max() <= REL * np.abs(z["signal"]).max()
+
+
 def test_oracle_feature_map_and_decode_primitives(oracle, golden_dir):
     z = np.load(os.path.join(golden_dir, "primitives.npz"))
     du = oracle.unit_norm(z["d_raw"])
