@@ -701,8 +701,42 @@ def multiband_full_fixture(mp, norm, steps=3, n_atoms=1024):
           f"recon error energy {float(((xt - rec) ** 2).sum() / (xt ** 2).sum()):.4f}")
 
 
+def dictionary_step_headline_fixture(mp, norm):
+    """dictionary_learning_step (:348-419) at the headline dictionary and segment length: 512 x 512, 4 x 32768 samples, 16 steps
+    (64 events, ~60 atoms used, several dependency levels).  The dictionary is regenerated from its seed; stored: the
+    signal, the reference's picks with their top-2 values, float64 checksums of the new dictionary and the rows of the
+    first sixteen atoms used."""
+    A, L, N, B, K, n_ev, seed = 512, 512, 32768, 4, 16, 48, 2505
+    d = synth.make_dictionary(A, L, seed=seed)
+    x = synth.make_segments(B, N, d, n_events=n_ev, seed=seed)
+    with torch.no_grad():
+        d_in = torch.from_numpy(d.copy())
+        d_new = mp.dictionary_learning_step(torch.from_numpy(x)[:, None, :], d_in, n_steps=K).numpy()
+        assert np.array_equal(d_in.numpy(), d)
+        enc = run_encode(mp, torch.from_numpy(x)[:, None, :], torch.from_numpy(d), K)
+    gap = (enc["top2"][..., 0] - enc["top2"][..., 1]) / np.abs(enc["top2"][..., 0])
+    used = enc["flat_order"][:, 0]
+    _, first = np.unique(used, return_index=True)
+    rows = used[np.sort(first)][:16]                      # the first sixteen atoms in first-selection order
+    du = norm.unit_norm(torch.from_numpy(d)).numpy()
+    np.savez_compressed(os.path.join(HERE, "dl_c2shape_512x512_n32768_b4_k16.npz"), signal=x, seed=np.int64(seed),
+                        shape=np.array([A, L, N, B, K], dtype=np.int64), atom=enc["atom"], lag=enc["lag"], top2=enc["top2"],
+                        d_unit_sum=np.float64(du.astype(np.float64).sum()), d_unit_head=du[:2].astype(np.float32),
+                        d_new_sum=np.float64(d_new.astype(np.float64).sum()),
+                        d_new_abs_sum=np.float64(np.abs(d_new.astype(np.float64)).sum()),
+                        d_new_rows=d_new[rows], d_new_row_index=rows.astype(np.int64),
+                        n_used=np.int64(len(np.unique(used))))
+    print(f"  dl_c2shape: {len(np.unique(used))} atoms used, min relative top-2 gap {gap.min():.3e}, "
+          f"|d_new - unit_norm(d)| max {np.abs(d_new - du).max():.3f}")
+
+
 if __name__ == "__main__":
-    if len(sys.argv) > 1 and sys.argv[1] == "model_full":   # mp.py:92's real configuration
+    if len(sys.argv) > 1 and sys.argv[1] == "dl_headline":
+        torch.manual_seed(0)
+        torch.set_num_threads(8)
+        _mp, _conv, _norm, _stft, _ns = load_reference()
+        dictionary_step_headline_fixture(_mp, _norm)
+    elif len(sys.argv) > 1 and sys.argv[1] == "model_full":   # mp.py:92's real configuration
         torch.manual_seed(0)
         torch.set_num_threads(8)
         _mp, _conv, _norm, _stft, _ns = load_reference()

@@ -140,6 +140,21 @@ def test_oracle_local_contrast_norm_matches_reference(oracle, golden_dir, name):
         assert not (np.array_equal(plain["atom"], out["atom"]) and np.array_equal(plain["lag"], out["lag"]))
 
 
+def test_oracle_dictionary_learning_step_at_the_headline_shape(oracle, golden_dir):
+    """The oracle's dictionary_learning_step against the reference's at 512 x 512, 4 x 32768 samples, 16 steps (59 atoms used;
+    one pick at a relative top-2 gap of 8.0e-5, which the oracle resolves as the reference does): picks first, then the new
+    dictionary by checksums and rows."""
+    z = np.load(os.path.join(golden_dir, "dl_c2shape_512x512_n32768_b4_k16.npz"))
+    A, L, N, B, K = [int(v) for v in z["shape"]]
+    d_raw = synth.make_dictionary(A, L, seed=int(z["seed"]))
+    enc = oracle.encode(z["signal"], oracle.unit_norm(d_raw), K)
+    assert np.array_equal(enc["atom"], z["atom"]) and np.array_equal(enc["lag"], z["lag"])
+    d_new = oracle.dictionary_learning_step(z["signal"], d_raw, K)
+    assert np.abs(d_new[z["d_new_row_index"]] - z["d_new_rows"]).max() <= 2e-6
+    assert abs(d_new.astype(np.float64).sum() - float(z["d_new_sum"])) <= 1e-3
+    assert int(z["n_used"]) == len(np.unique(z["atom"]))
+
+
 def test_oracle_local_contrast_norm_at_the_headline_shape(oracle, golden_dir):
     """The reference's sparse_code(local_contrast_norm=True) on the headline dictionary and segment length (512 x 512,
     2 x 32768 samples, 8 steps; dictionary regenerated from its seed and checked against the fixture's checksums):
