@@ -701,6 +701,26 @@ def multiband_full_fixture(mp, norm, steps=3, n_atoms=1024):
           f"recon error energy {float(((xt - rec) ** 2).sum() / (xt ** 2).sum()):.4f}")
 
 
+def sparse_feature_map_mid_fixture(mp):
+    """sparse_feature_map (:68-125) and its gradient at a size where the map has many cells per segment (128 x 256 dictionary,
+    2 x 8192 samples, 12 steps: 4 atom tiles x 128 lag blocks): nonzero coordinates and values, residual, d/d signal of
+    <fm, W> + <residual, V> (W, V from numpy's PCG64(56), redrawn by the test)."""
+    A, L, N, B, K = 128, 256, 8192, 2, 12
+    d = synth.make_dictionary(A, L, seed=2808)
+    x = synth.make_segments(B, N, d, n_events=14, seed=2808)
+    rng = np.random.default_rng(56)
+    W = rng.standard_normal((B, A, N)).astype(np.float32)
+    V = rng.standard_normal((B, 1, N)).astype(np.float32)
+    xs = torch.from_numpy(x).clone().requires_grad_(True)
+    fm, res = mp.sparse_feature_map(xs, torch.from_numpy(d), n_steps=K, return_residual=True)
+    ((fm * torch.from_numpy(W)).sum() + (res * torch.from_numpy(V)).sum()).backward()
+    nz = torch.nonzero(fm.detach())
+    np.savez_compressed(os.path.join(HERE, "sparse_feature_map_mid.npz"), signal=x, d_raw=d, nz_index=nz.numpy(),
+                        nz_value=fm.detach()[nz[:, 0], nz[:, 1], nz[:, 2]].numpy(), residual=res.detach().numpy()[:, 0, :],
+                        n_steps=np.int64(K), grad_signal=xs.grad.numpy(), wv_seed=np.int64(56))
+    print(f"  sparse_feature_map_mid: {nz.shape[0]} nonzero cells, |grad| max {float(xs.grad.abs().max()):.3e}")
+
+
 def dictionary_step_headline_fixture(mp, norm):
     """dictionary_learning_step (:348-419) at the headline dictionary and segment length: 512 x 512, 4 x 32768 samples, 16 steps
     (64 events, ~60 atoms used, several dependency levels).  The dictionary is regenerated from its seed; stored: the
@@ -731,7 +751,11 @@ def dictionary_step_headline_fixture(mp, norm):
 
 
 if __name__ == "__main__":
-    if len(sys.argv) > 1 and sys.argv[1] == "dl_headline":
+    if len(sys.argv) > 1 and sys.argv[1] == "sfm_mid":
+        torch.manual_seed(0)
+        torch.set_num_threads(8)
+        sparse_feature_map_mid_fixture(load_reference()[0])
+    elif len(sys.argv) > 1 and sys.argv[1] == "dl_headline":
         torch.manual_seed(0)
         torch.set_num_threads(8)
         _mp, _conv, _norm, _stft, _ns = load_reference()

@@ -240,6 +240,28 @@ def test_sparse_feature_map_gradient_matches_reference(golden_dir):
     assert recon.grad is not None and torch.isfinite(recon.grad).all() and recon.grad.abs().sum() > 0
 
 
+def test_sparse_feature_map_mid_size_value_and_gradient_match_reference(golden_dir):
+    """sparse_feature_map at 128 x 256, 2 x 8192 samples, 12 steps (four atom tiles x 128 lag blocks per segment) against
+    the reference's own run: nonzero cells and values, residual, and d/d signal of <fm, W> + <residual, V> through the
+    event-replaying backward."""
+    z = np.load(os.path.join(golden_dir, "sparse_feature_map_mid.npz"))
+    B, N = z["signal"].shape
+    A = z["d_raw"].shape[0]
+    rng = np.random.default_rng(int(z["wv_seed"]))
+    W = torch.from_numpy(rng.standard_normal((B, A, N)).astype(np.float32)).to(DEV)
+    V = torch.from_numpy(rng.standard_normal((B, 1, N)).astype(np.float32)).to(DEV)
+    d = torch.from_numpy(z["d_raw"]).to(DEV)
+    x = torch.from_numpy(z["signal"]).to(DEV).requires_grad_(True)
+    fm, res = mp.sparse_feature_map(x, d, n_steps=int(z["n_steps"]), return_residual=True)
+    nz = torch.nonzero(fm.detach()).cpu().numpy()
+    assert np.array_equal(nz, z["nz_index"])
+    vals = fm.detach()[nz[:, 0], nz[:, 1], nz[:, 2]].cpu().numpy()
+    assert np.abs(vals - z["nz_value"]).max() <= 1e-5 * np.abs(z["nz_value"]).max()
+    assert np.abs(res.detach()[:, 0].cpu().numpy() - z["residual"]).max() <= REL * np.abs(z["signal"]).max()
+    ((fm * W).sum() + (res * V).sum()).backward()
+    assert np.abs(x.grad.cpu().numpy() - z["grad_signal"]).max() <= 2e-4 * np.abs(z["grad_signal"]).max()
+
+
 def test_sparse_coding_loss_matches_reference(golden_dir):
     """modules/matchingpursuit.py:128-146 against the reference's own value and d loss / d recon; both the
     event-built (no gradient) and the dense (gradient) evaluation."""
