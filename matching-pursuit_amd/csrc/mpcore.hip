@@ -95,6 +95,7 @@ constexpr int LAGS_PER_WAVE = 64;   // one cell = TA atoms x 64 lags, owned by o
 constexpr int WAVES = 4;            // wavefronts per workgroup
 constexpr int KC_MAX = 512;         // atom samples staged in LDS per chunk
 constexpr int MAXCONT = 32;         // FFT path: inexact contender cells per segment per iteration
+constexpr int SPLIT_REFINE_ROUNDS = 4;  // ... times this many rounds where transforms are split (fft_iteration)
 constexpr int MP_FLAG_INTERNAL_ONE_STREAM = 1 << 30;  // set by encode_impl: the batch is not split
 constexpr int MP_FLAG_INTERNAL_COHERENCE = 1 << 29;   // set by mp_coherence_f32: |.| screen only
 // ------------------------------------------------------------------------------------------------
@@ -1675,6 +1676,14 @@ Geom make_geom_for(int64_t B, int64_t N, int64_t A, int64_t L, int path, int fla
         default: return fail(MP_ERR_UNSUPPORTED, "FFT size out of range%s"); \
     }
 
+// split transforms (FftGeom::split = log2 of the parts)
+#define MP_SPLIT_DISPATCH(SPLIT, CALL)                               \
+    switch (SPLIT) {                                                 \
+        case 1: { constexpr int Q = 2; CALL; } break;                \
+        case 2: { constexpr int Q = 4; CALL; } break;                \
+        default: return fail(MP_ERR_UNSUPPORTED, "FFT split out of range%s"); \
+    }
+
 template <typename K>
 int fft_lds_attr(K kern, size_t bytes) {
     if (bytes > 64 * 1024)
@@ -1753,9 +1762,9 @@ int clear_async(const ClearList &c, hipStream_t st) {
 int fft_setup(const Geom &g, const Workspace &w, const float *du, int flags, int K, hipStream_t st) {
     FftGeom f;
     if (!make_fft_geom(g, &f))
-        return fail(MP_ERR_UNSUPPORTED, "MP_PATH_FFT: atoms longer than 10859 samples need MP_PATH_INCREMENTAL%s");
+        return fail(MP_ERR_UNSUPPORTED, "MP_PATH_FFT: atoms longer than 21782 samples need MP_PATH_INCREMENTAL%s");
     if (g.B > 65535) return fail(MP_ERR_ARG, "MP_PATH_FFT: batch > 65535 per call%s");
-    const size_t lds = (size_t)(f.split ? f.M / 2 : f.M) * sizeof(cpx);
+    const size_t lds = (size_t)(f.M >> f.split) * sizeof(cpx);
     const int64_t n_cells = (int64_t)g.NBLK * g.NAT;
     const int npairs = g.NAT * f.NPT;
     int rc;
@@ -1768,16 +1777,18 @@ int fft_setup(const Geom &g, const Workspace &w, const float *du, int flags, int
     cl.add(w.skip, (size_t)g.B * 4 * sizeof(unsigned));
     if (w.pctl && K >= 2) cl.add(w.pctl, persist_ctl_bytes(g.B, K));   // the persistent form's control block and queue
     if ((rc = clear_async(cl, st))) return rc;
-    if (f.split) {  // long atoms: two half-size transforms per M-point transform (mpfft.inc)
+    if (f.split) {  // long atoms: two or four 2^14-point transforms per M-point transform (mpfft.inc)
         constexpr int LH = SPLIT_LOGH;
-        const int H = f.M / 2;
+        const int H = f.M >> f.split;
         hipLaunchKernelGGL(fft_twiddle_kernel, dim3((H + 255) / 256), dim3(256), 0, st, w.tw, H);
         hipLaunchKernelGGL(fft_twiddle_kernel, dim3((f.M + 255) / 256), dim3(256), 0, st, w.tw + H, f.M);
         HIP_TRY(hipGetLastError());
-        if ((rc = fft_lds_attr(fft_dict_split_kernel<LH>, lds))) return rc;
-        if ((rc = fft_lds_attr(fft_window_split_kernel<LH>, lds))) return rc;
-        if ((rc = fft_lds_attr(fft_correlate_split_kernel<LH>, lds))) return rc;
-        hipLaunchKernelGGL(fft_dict_split_kernel<LH>, dim3(npairs, 2), dim3(256), lds, st, du, g.A, g.L, w.tw, w.pspec);
+        MP_SPLIT_DISPATCH(f.split, {
+            if ((rc = fft_lds_attr(fft_dict_split_kernel<LH, Q>, lds))) return rc;
+            if ((rc = fft_lds_attr(fft_window_split_kernel<LH, Q>, lds))) return rc;
+            if ((rc = fft_lds_attr(fft_correlate_split_kernel<LH, Q>, lds))) return rc;
+            hipLaunchKernelGGL((fft_dict_split_kernel<LH, Q>), dim3(npairs, Q), dim3(256), lds, st, du, g.A, g.L, w.tw, w.pspec);
+        })
         HIP_TRY(hipGetLastError());
         const size_t lds_ref_s = lds_bytes(g);
         if (!(flags & MP_FLAG_NO_DMA)) { if ((rc = fft_lds_attr(fft_refine_kernel<true>, lds_ref_s))) return rc; }
@@ -1808,7 +1819,7 @@ int fft_iteration(const Geom &g, const Workspace &w, const float *du, int K, int
     const float tau = fft_tau(f.logM).tau;
     // split transforms: the four-kernel form between screens (the window kernel makes the next spectrum)
     if (f.split) flags = (flags | MP_FLAG_FFT_UNFUSED) & ~(MP_FLAG_FFT_FUSED | MP_FLAG_FFT_QUARTER);
-    const size_t lds = (size_t)(f.split ? f.M / 2 : f.M) * sizeof(cpx);
+    const size_t lds = (size_t)(f.M >> f.split) * sizeof(cpx);
     const int64_t n_cells = (int64_t)g.NBLK * g.NAT;
     const bool dma = !(flags & MP_FLAG_NO_DMA);
     const size_t lds_ref = lds_bytes(g);
@@ -1856,8 +1867,10 @@ int fft_iteration(const Geom &g, const Workspace &w, const float *du, int K, int
         const int nw = k == 0 ? f.NW : 1;
         g_prof.begin(PROF_SELECT, st);
         if (f.split) {
-            hipLaunchKernelGGL(fft_window_split_kernel<SPLIT_LOGH>, dim3(nw, (unsigned)g.B, 2), dim3(1024), lds, st, w.res,
-                               g.Ns, dirty, w.tw, w.xspec, w.wnorm, f.V, f.NW, (const float *)w.dscale);
+            MP_SPLIT_DISPATCH(f.split, {
+                hipLaunchKernelGGL((fft_window_split_kernel<SPLIT_LOGH, Q>), dim3(nw, (unsigned)g.B, Q), dim3(1024), lds, st, w.res,
+                                   g.Ns, dirty, w.tw, w.xspec, w.wnorm, f.V, f.NW, (const float *)w.dscale);
+            })
         } else if (k == 0 || !fused_tail) {
             MP_FFT_DISPATCH(f.logM, {
                 hipLaunchKernelGGL(fft_window_kernel<LG>, dim3(nw, (unsigned)g.B), dim3(256), lds, st, w.res, g.Ns,
@@ -1877,14 +1890,17 @@ int fft_iteration(const Geom &g, const Workspace &w, const float *du, int K, int
             const bool seg_fast = (size_t)g.NAT * f.NPT * f.M * sizeof(cpx) > (size_t)16 << 20;
             const unsigned gwp = nw * (16 / (C::SLOTS * pps));
             const dim3 grid = seg_fast ? dim3(xcd_grid(g.B, (int64_t)gwp * g.NAT)) : dim3(gwp, g.NAT, (unsigned)g.B);
-            if ((rc = fft_lds_attr(fft_screen_split_kernel<SPLIT_LOGH>, lds_s))) return rc;
-            hipLaunchKernelGGL(fft_screen_split_kernel<SPLIT_LOGH>, grid, dim3(C::WG), lds_s, st, w.xspec, w.pspec,
+            auto kern = f.split == 2 ? fft_screen_split4_kernel<SPLIT_LOGH> : fft_screen_split_kernel<SPLIT_LOGH>;
+            if ((rc = fft_lds_attr(kern, lds_s))) return rc;
+            hipLaunchKernelGGL(kern, grid, dim3(C::WG), lds_s, st, w.xspec, w.pspec,
                                w.tw, dirty, w.wnorm, w.keys, w.ceps, g.N, g.A, g.NBLK, g.NAT, f.V, f.NW, tau, pps,
                                seg_fast ? (int)g.B : 0);
         } else if (f.split) {
-            hipLaunchKernelGGL(fft_correlate_split_kernel<SPLIT_LOGH>, dim3(2 * nw, g.NAT, (unsigned)g.B), dim3(256), lds, st,
-                               w.xspec, w.pspec, w.tw, dirty, w.wnorm, w.keys, w.ceps, g.N, g.A, g.NBLK, g.NAT, f.V,
-                               f.NW, tau);
+            MP_SPLIT_DISPATCH(f.split, {
+                hipLaunchKernelGGL((fft_correlate_split_kernel<SPLIT_LOGH, Q>), dim3(Q * nw, g.NAT, (unsigned)g.B), dim3(256), lds, st,
+                                   w.xspec, w.pspec, w.tw, dirty, w.wnorm, w.keys, w.ceps, g.N, g.A, g.NBLK, g.NAT, f.V,
+                                   f.NW, tau);
+            })
         } else
         MP_FFT_DISPATCH(f.logM, {
             if (LG >= 10 && !(flags & MP_FLAG_FFT_SIMPLE)) {
@@ -1983,13 +1999,22 @@ int fft_iteration(const Geom &g, const Workspace &w, const float *du, int K, int
             // select-A merged into the refinement launch when select-B is the kernel that clears the slots
             // afterwards and a segment's keys are few enough for every workgroup to scan them
             const bool scan_refine = b_tail && !(flags & (MP_FLAG_REFINE_MFMA | MP_FLAG_FFT_UNFUSED)) && n_cells <= 16384;
+            // Split transforms (atoms of 5399 .. 21782 samples): the chains' own rounding bound grows with the atom (W_a ~ 0.58 L
+            // u ||window||, section 4b), so on noise-like residuals a step can meet more contender cells than the MAXCONT slots --
+            // and an overflow costs the whole segment a second encode on the MFMA schedule (2048 x 16384 atoms on noise: two of
+            // four segments, scripts/longest_atoms_time.py).  Up to four rounds of select-A + refine there: a round's exact keys go
+            // back into the cells, the next round's lower bound rises with them and lists what is left; a round that finds
+            // nothing leaves at once (two launches, ~15 us a round, against steps of 0.3 .. 1 ms).
+            const int rounds = (f.split && !scan_refine) ? SPLIT_REFINE_ROUNDS : 1;
+            for (int round = 0; round < rounds; ++round) {
             if (scan_refine) {
                 const size_t lds_win = (size_t)(round_up(g.L, 64) + 128) * sizeof(float);
                 hipLaunchKernelGGL(fft_scan_refine_kernel, dim3((unsigned)g.B, 8), dim3(SR_WG), lds_win, st, w.keys, w.ceps,
                                    n_cells, w.res, du, w.cont, w.ncont, w.ekeys, w.overflow, g.N, g.A, g.L, g.Ns, g.NAT);
             } else
                 hipLaunchKernelGGL(fft_select_a_kernel, dim3((unsigned)g.B), dim3(1024), 0, st, w.keys, w.ceps, n_cells,
-                                   w.cont, w.ncont, w.ekeys, w.overflow);
+                                   w.cont, w.ncont, w.ekeys, w.overflow, round + 1 == rounds ? 1 : 0,
+                                   round > 0 ? w.keys : (u64 *)nullptr, round > 0 ? w.ceps : (float *)nullptr);
             if (scan_refine) {
             } else if (flags & MP_FLAG_REFINE_MFMA) {
                 if (dma)
@@ -2005,6 +2030,7 @@ int fft_iteration(const Geom &g, const Workspace &w, const float *du, int K, int
                 const unsigned ry = (unsigned)std::min<int64_t>(MAXCONT, std::max<int64_t>(1, 2 * (int64_t)num_cus() / (2 * g.B)));
                 hipLaunchKernelGGL(fft_refine_chain_kernel, dim3(2, ry, (unsigned)g.B), dim3(256), lds_win, st, w.res, du,
                                    w.cont, w.ncont, w.ekeys, g.N, g.A, g.L, g.Ns, g.NAT);
+            }
             }
             if (b_tail) {
                 MP_FFT_DISPATCH(f.logM, {

@@ -233,7 +233,7 @@ def workspace_bytes(B, N, A, L, K, path):
     return int(n)
 
 
-FFT_MAX_ATOM = 10859    # longest atom whose 3L+190-point transform fits LDS whole (<= 5398) or as two halves
+FFT_MAX_ATOM = 21782    # longest atom whose 3L+190-point transform fits LDS whole (<= 5398), as two halves (<= 10859) or four quarters
 FFT_MAX_BATCH = 65535   # segments per mp_encode_f32 call on MP_PATH_FFT (the wrapper chunks larger batches)
 
 

@@ -1,11 +1,12 @@
 #!/bin/bash
 # Round-4 profiling passes (run on the GPU box via gpurun; summaries are then copied into profiles/ by
 # scripts/summarize_profiles.py / summarize_c4.py / summarize_kernels.py):
-#   which = persist | fft | c4 | long | lcn | all
+#   which = persist | fft | c4 | long | lcn | longest | all
 #   persist, fft : bench.py on the FFT schedule (the one-launch default; launch per step on one stream): kernel trace + PMC passes
 #   c4           : BASELINE configs[3] with the lazy screen (scripts/c4_traffic.py 128 256, SURVEY 8(d)'s 768 planted events)
 #   long         : the split-transform screen, 1024 atoms of 8192 samples, 8 x 32768 (scripts/long_atom_one.py)
 #   lcn          : the local-contrast-norm schedule at the headline shape (scripts/lcn_headline.py)
+#   longest      : the four-quarter screen, 2048 atoms of 16384 samples, 4 x 32768, 32 steps (scripts/longest_atoms_time.py)
 # Counters run in their own passes (--pmc alone), never with a trace.
 set -uo pipefail
 cd "$(dirname "$0")/.."
@@ -36,5 +37,6 @@ if want c4; then
 fi
 if want long; then passes r04_long_atom python3 scripts/long_atom_one.py 32768 8; fi
 if want lcn; then passes r04_lcn python3 scripts/lcn_headline.py 64 64; fi
-find gpurun_out/r04_persist gpurun_out/r04_fft gpurun_out/r04_c4 gpurun_out/r04_long_atom gpurun_out/r04_lcn -name "*_agent_info.csv" -delete 2>/dev/null
+if want longest; then passes r04_longest_atom python3 scripts/longest_atoms_time.py 4 32 "fft ("; fi
+find gpurun_out/r04_persist gpurun_out/r04_fft gpurun_out/r04_c4 gpurun_out/r04_long_atom gpurun_out/r04_lcn gpurun_out/r04_longest_atom -name "*_agent_info.csv" -delete 2>/dev/null
 du -sh gpurun_out/r04_* 2>/dev/null

@@ -39,8 +39,8 @@ for case in range(n_cases):
     if case % 10 == 3:   # more than 16384 cells per segment: up to 65536 the persistent form with the fused whole-cell step 0
                          # (1024- to 4096-point transforms, the default since round 3), the launch-per-step fused select beyond / at short atoms
         A = int(rng.choice([1000, 1024, 1500])); L = int(rng.choice([32, 64, 600])); N = int(rng.integers(36000, 48000)); B = 2; K = 3
-    if case % 10 == 4:   # atoms beyond 5398 samples: split transforms (two 2^14-point halves per 2^15-point transform)
-        A = int(rng.integers(1, 10)); L = int(rng.choice([5399, 8192, 10859])); N = int(rng.integers(L // 2, 30000)); B = int(rng.choice([1, 2, 9])); K = 3
+    if case % 10 == 4:   # atoms beyond 5398 samples: split transforms (two / four 2^14-point parts per 2^15- / 2^16-point transform)
+        A = int(rng.integers(1, 10)); L = int(rng.choice([5399, 8192, 10859, 10860, 16384, 21782])); N = int(rng.integers(L // 2, 30000)); B = int(rng.choice([1, 2, 9])); K = 3
     d = synth.make_dictionary(A, L, seed=1000 + case)
     x = synth.make_segments(B, N, d, n_events=min(3 * K, 12), seed=5000 + case) if N > L else \
         rng.standard_normal((B, N)).astype(np.float32)

@@ -55,6 +55,8 @@ SHAPES = {
     "split_batch": (20, 48, 900, 9, 6, 5, 18),   # B >= 8: two sub-batches on forked streams, 4 + 5 segments
     "long_atoms": (6, 6000, 9000, 2, 5, 3, 19),  # L > 5398: 2^15-point transforms as two 2^14-point halves
     "long_atoms_two_windows": (5, 7000, 30000, 2, 4, 3, 20),  # ... and a full pass of two windows; odd atom count
+    "longest_atoms": (5, 16384, 20000, 2, 4, 3, 21),  # L > 10859: 2^16-point transforms as four 2^14-point quarters (e_2023_12_18's atom_size)
+    "longest_atoms_two_windows": (4, 12000, 70000, 1, 3, 3, 22),  # ... and a full pass of two windows
 }
 
 
@@ -94,12 +96,17 @@ def test_feature_map_bitwise(oracle, shape):
     assert np.array_equal(got, want), f"max |diff| = {np.abs(got - want).max()}"
 
 
+_ORACLE_ENCODES = {}   # shape -> the oracle's events (one CPU encode per shape, not one per schedule)
+
+
 @pytest.mark.parametrize("pname,path,flags", PATHS)
 @pytest.mark.parametrize("shape", list(SHAPES))
 def test_encode_bitwise_vs_oracle(oracle, shape, pname, path, flags):
     d, x, K = _inputs(shape)
     du = oracle.unit_norm(d)
-    want = oracle.encode(x, du, K)
+    if shape not in _ORACLE_ENCODES:
+        _ORACLE_ENCODES[shape] = oracle.encode(x, du, K)
+    want = _ORACLE_ENCODES[shape]
     atom, lag, gain, residual = _gpu_encode(x, du, K, path, flags)
     assert np.array_equal(atom, want["atom"]), (atom, want["atom"])
     assert np.array_equal(lag, want["lag"]), (lag, want["lag"])
@@ -374,14 +381,14 @@ def test_bad_arguments_fail_loudly():
         nat.encode(torch.zeros(1, 64), du, 1)  # CPU tensor
     with pytest.raises(nat.NativeError):
         nat.encode(torch.zeros(1, 64, device=DEV), du, 1, path=77)
-    with pytest.raises(nat.NativeError):  # a transform must fit LDS whole or as two halves: atoms > 10859 samples
-        nat.encode(torch.zeros(1, 16000, device=DEV), torch.rand(2, 11000, device=DEV), 1, path=nat.MP_PATH_FFT)
+    with pytest.raises(nat.NativeError):  # a transform must fit LDS whole, as two halves or as four quarters: atoms > 21782 samples
+        nat.encode(torch.zeros(1, 30000, device=DEV), torch.rand(2, 22000, device=DEV), 1, path=nat.MP_PATH_FFT)
     with pytest.raises(nat.NativeError):  # flat (atom, lag) indices are 32-bit: A * N must stay below 2^32
         nat.encode(torch.zeros(1, 4096, device=DEV), torch.zeros(1 << 20, 1, device=DEV), 1, path=nat.MP_PATH_INCREMENTAL)
     with pytest.raises(nat.NativeError):
         nat.encode_lcn(torch.zeros(1, 4096, device=DEV), torch.zeros(1 << 20, 1, device=DEV), 1)
     # ... and the default schedule falls back to the incremental one for those
-    a, l, g, r = nat.encode_checked(torch.rand(1, 16000, device=DEV), nat.unit_norm(torch.rand(2, 11000, device=DEV)), 1)
+    a, l, g, r = nat.encode_checked(torch.rand(1, 30000, device=DEV), nat.unit_norm(torch.rand(2, 22000, device=DEV)), 1)
     assert a.shape == (1, 1) and not torch.isnan(g).any()
 
 
