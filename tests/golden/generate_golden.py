@@ -101,6 +101,9 @@ ENCODE_CASES = [
     # configs[1]'s shape at the HEADLINE's depth (K = 64, SURVEY 8(d)'s 3 K planted events): whatever near-ties the one
     # seed holds are kept and counted by the tests, not avoided (top2_index says which cell the runner-up was)
     ("c2shape_512x512_n32768_b4_k64", 512, 512, 32768, 4, 64, 192, 414),
+    # atoms beyond 10859 samples (experiments/archive/e_2023_12_18/experiment.py:23 uses 16384): every transform of the FFT
+    # schedule runs as four quarters
+    ("longest_5x16384_n24000_b2_k4", 5, 16384, 24000, 2, 4, 5, 808),
 ]
 
 

@@ -143,7 +143,8 @@ def _check_against_reference_fixture(z, du, got):
 @pytest.mark.parametrize("sname,path,flags,lazy", GOLDEN_SCHEDULES)
 @pytest.mark.parametrize("name", ["encode_c1_16x256_n8192_b1_k8", "encode_mid_64x128_n4096_b3_k16",
                                   "encode_ragged_24x100_n1000_b2_k12",
-                                  "encode_c2shape_512x512_n32768_b2_k12", "encode_long_6x6000_n14000_b2_k5"])
+                                  "encode_c2shape_512x512_n32768_b2_k12", "encode_long_6x6000_n14000_b2_k5",
+                                  "encode_longest_5x16384_n24000_b2_k4"])
 def test_encode_matches_reference_golden(golden_dir, name, sname, path, flags, lazy):
     """Against vectors produced by the real reference (tests/golden/generate_golden.py), on every schedule -- the
     configs[1]-shape fixture meets the persistent FFT form (the library default there) directly, not through the oracle."""

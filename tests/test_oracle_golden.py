@@ -29,7 +29,8 @@ def test_fixtures_present(golden_dir):
 
 @pytest.mark.parametrize("name", ["encode_c1_16x256_n8192_b1_k8", "encode_mid_64x128_n4096_b3_k16",
                                   "encode_ragged_24x100_n1000_b2_k12",
-                                  "encode_c2shape_512x512_n32768_b2_k12", "encode_long_6x6000_n14000_b2_k5"])
+                                  "encode_c2shape_512x512_n32768_b2_k12", "encode_long_6x6000_n14000_b2_k5",
+                                  "encode_longest_5x16384_n24000_b2_k4"])
 def test_oracle_encode_matches_reference(oracle, golden_dir, name):
     z = np.load(os.path.join(golden_dir, name + ".npz"))
     d_raw = _raw_dict(z)
