@@ -97,13 +97,16 @@ SCREEN_KERNELS = {
 def screen_pair_loop(kind, log_m, lib=LIB):
     """The screen's loop over atom pairs in the built code object: one trip = one M-point transform of X * P by the
     workgroup's threads (16 points per thread), spectrum product, transform and running maxima.  It is the largest loop
-    whose body holds exactly the sixteen pair-spectrum loads of one transform and no matrix instruction.
+    whose body holds exactly the pair-spectrum loads of one transform (sixteen points per thread) and no matrix instruction.
     -> dict(valu, packed, lds, barriers, instructions) per trip and thread."""
     insts = kernel_instructions(SCREEN_KERNELS[(kind, log_m)], lib)
     best = None
     for lo, hi in loops(insts):
         body = insts[lo:hi + 1]
-        if sum(op.startswith("global_load") for _, op, _ in body) != 16 or any("mfma" in op for _, op, _ in body):
+        # (sixteen complex points per thread: sixteen 8-byte loads, or eight 16-byte ones where the 2048-point transform takes
+        #  adjacent first-pass columns)
+        if sum(2 if op == "global_load_dwordx4" else 1 for _, op, _ in body if op.startswith("global_load")) != 16 \
+                or any("mfma" in op for _, op, _ in body):
             continue
         if best is None or hi - lo > best[1] - best[0]:
             best = (lo, hi)
