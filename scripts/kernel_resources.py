@@ -94,22 +94,28 @@ SCREEN_KERNELS = {
 }
 
 
+def pair_loop_range(insts):
+    """(first, last) instruction index of the largest loop that loads exactly one transform's pair spectrum -- sixteen complex
+    points per thread: sixteen 8-byte loads, or eight 16-byte ones where the 2048-point transform takes adjacent first-pass
+    columns -- and holds no matrix instruction; None if there is none."""
+    best = None
+    for lo, hi in loops(insts):
+        body = insts[lo:hi + 1]
+        if sum(2 if op == "global_load_dwordx4" else 1 for _, op, _ in body if op.startswith("global_load")) != 16 \
+                or any("mfma" in op for _, op, _ in body):
+            continue
+        if best is None or hi - lo > best[1] - best[0]:
+            best = (lo, hi)
+    return best
+
+
 def screen_pair_loop(kind, log_m, lib=LIB):
     """The screen's loop over atom pairs in the built code object: one trip = one M-point transform of X * P by the
     workgroup's threads (16 points per thread), spectrum product, transform and running maxima.  It is the largest loop
     whose body holds exactly the pair-spectrum loads of one transform (sixteen points per thread) and no matrix instruction.
     -> dict(valu, packed, lds, barriers, instructions) per trip and thread."""
     insts = kernel_instructions(SCREEN_KERNELS[(kind, log_m)], lib)
-    best = None
-    for lo, hi in loops(insts):
-        body = insts[lo:hi + 1]
-        # (sixteen complex points per thread: sixteen 8-byte loads, or eight 16-byte ones where the 2048-point transform takes
-        #  adjacent first-pass columns)
-        if sum(2 if op == "global_load_dwordx4" else 1 for _, op, _ in body if op.startswith("global_load")) != 16 \
-                or any("mfma" in op for _, op, _ in body):
-            continue
-        if best is None or hi - lo > best[1] - best[0]:
-            best = (lo, hi)
+    best = pair_loop_range(insts)
     if best is None:
         raise RuntimeError(f"no pair loop found in {SCREEN_KERNELS[(kind, log_m)]}")
     body = insts[best[0]:best[1] + 1]
