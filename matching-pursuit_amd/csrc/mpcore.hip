@@ -2004,7 +2004,8 @@ int fft_iteration(const Geom &g, const Workspace &w, const float *du, int K, int
             // and an overflow costs the whole segment a second encode on the MFMA schedule (2048 x 16384 atoms on noise: two of
             // four segments, scripts/longest_atoms_time.py).  Up to four rounds of select-A + refine there: a round's exact keys go
             // back into the cells, the next round's lower bound rises with them and lists what is left; a round that finds
-            // nothing leaves at once (two launches, ~15 us a round, against steps of 0.3 .. 1 ms).
+            // nothing -- or follows a round that listed all its contenders -- leaves at once (two launches, ~8 us a round, against
+            // steps of 0.3 .. 1 ms).
             const int rounds = (f.split && !scan_refine) ? SPLIT_REFINE_ROUNDS : 1;
             for (int round = 0; round < rounds; ++round) {
             if (scan_refine) {
