@@ -1005,32 +1005,92 @@ __global__ __launch_bounds__(256) void lcn_select_subtract_kernel(
 }
 
 // ------------------------------------------------------------------------------------------------
-// scatter_segments (modules/matchingpursuit.py:20-58): one workgroup per segment walks the event
-// list in order; events of a segment may overlap, so they are applied one after another.
+// scatter_segments (modules/matchingpursuit.py:20-58): events of a segment may overlap, and the reference adds them
+// to the output one after another -- per SAMPLE the order of the additions is the order of the list, and that is all the
+// result depends on.  So the kernel is driven by the output: a workgroup owns SCATTER_CHUNK samples of one segment
+// (4 per thread, in registers), compacts -- in list order, a block of SCATTER_EB events at a time -- the events of its
+// segment that reach into its chunk, and every thread adds the ones covering its samples, in that order, with the same
+// two roundings (product, sum).  Round 1's form -- one workgroup per segment walking the WHOLE list, a dependent scalar
+// load per event, 64 workgroups on 256 CUs -- took 0.2 ms of a 3.5 ms sparse_code + scatter at the headline shape.
 // ------------------------------------------------------------------------------------------------
+constexpr int SCATTER_CHUNK = 4096;   // samples per workgroup (1024 threads x 4)
+constexpr int SCATTER_EB = 2048;      // events compacted per round
 template <bool ROWS>
-__global__ __launch_bounds__(256) void scatter_kernel(const float *__restrict__ rows,
-                                                      const int64_t *__restrict__ atom,
-                                                      const int64_t *__restrict__ batch,
-                                                      const int64_t *__restrict__ lag,
-                                                      const float *__restrict__ gain, int64_t n_events,
-                                                      const float *__restrict__ du, int64_t L,
-                                                      float *__restrict__ out, int64_t N) {
+__global__ __launch_bounds__(1024) void scatter_kernel(const float *__restrict__ rows,
+                                                       const int64_t *__restrict__ atom,
+                                                       const int64_t *__restrict__ batch,
+                                                       const int64_t *__restrict__ lag,
+                                                       const float *__restrict__ gain, int64_t n_events,
+                                                       const float *__restrict__ du, int64_t L,
+                                                       float *__restrict__ out, int64_t N) {
+    __shared__ int64_t s_lag[SCATTER_EB];
+    __shared__ int64_t s_src[SCATTER_EB];    // row offset (floats) of the event's atom / row
+    __shared__ float s_gain[SCATTER_EB];
+    __shared__ int s_wave[16];
+    __shared__ int s_n;
     const int64_t b = blockIdx.x;
+    const int64_t t0 = (int64_t)blockIdx.y * SCATTER_CHUNK;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     float *o = out + b * N;
-    for (int64_t e = 0; e < n_events; ++e) {
-        if (batch[e] != b) continue;  // uniform across the workgroup
-        const int64_t p = lag[e];
-        const float *src = ROWS ? rows + e * L : du + atom[e] * L;
-        const float g = ROWS ? 1.0f : gain[e];
-        for (int64_t s = threadIdx.x; s < L; s += 256) {
-            const int64_t t = p + s;
-            if (t >= 0 && t < N) {
-                const float v = ROWS ? src[s] : __fmul_rn(src[s], g);
-                o[t] = __fadd_rn(o[t], v);
+    float acc[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int64_t t = t0 + tid + 1024 * i;
+        acc[i] = t < N ? o[t] : 0.0f;
+    }
+    for (int64_t e0 = 0; e0 < n_events; e0 += SCATTER_EB) {
+        if (tid == 0) s_n = 0;
+        __syncthreads();
+        // order-preserving compaction, 1024 events per pass: ballot within the wavefront, wave totals through LDS
+        for (int64_t j0 = 0; j0 < SCATTER_EB && e0 + j0 < n_events; j0 += 1024) {
+            const int64_t e = e0 + j0 + tid;
+            bool hit = false;
+            int64_t p = 0;
+            if (e < n_events && batch[e] == b) {
+                p = lag[e];
+                hit = p + L > t0 && p < t0 + SCATTER_CHUNK;
+            }
+            const unsigned long long m = __ballot(hit);
+            if (lane == 0) s_wave[w] = __popcll(m);
+            __syncthreads();
+            int base = s_n;
+            for (int q = 0; q < w; ++q) base += s_wave[q];
+            if (hit) {
+                const int pos = base + __popcll(m & ((1ull << lane) - 1ull));
+                s_lag[pos] = p;
+                s_src[pos] = ROWS ? e * L : atom[e] * L;
+                s_gain[pos] = ROWS ? 1.0f : gain[e];
+            }
+            __syncthreads();
+            if (tid == 0) {
+                int tot = 0;
+                for (int q = 0; q < 16; ++q) tot += s_wave[q];
+                s_n += tot;
+            }
+            __syncthreads();
+        }
+        const int n = s_n;
+        const float *srcb = ROWS ? rows : du;
+        for (int q = 0; q < n; ++q) {
+            const int64_t p = s_lag[q];
+            const float *src = srcb + s_src[q];
+            const float g = s_gain[q];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int64_t t = t0 + tid + 1024 * i;
+                const int64_t s = t - p;
+                if (s >= 0 && s < L && t < N) {
+                    const float v = ROWS ? src[s] : __fmul_rn(src[s], g);
+                    acc[i] = __fadd_rn(acc[i], v);
+                }
             }
         }
-        __syncthreads();
+        __syncthreads();   // the lists are rebuilt by the next round
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int64_t t = t0 + tid + 1024 * i;
+        if (t < N) o[t] = acc[i];
     }
 }
 
@@ -2720,7 +2780,8 @@ int mp_scatter_f32(const int64_t *atom, const int64_t *batch, const int64_t *lag
     if (!atom || !batch || !lag || !gain || !dict_unit || !out || A <= 0 || L <= 0 || N <= 0 || B < 0 ||
         n_events < 0)
         return fail(MP_ERR_ARG, "mp_scatter_f32: bad arguments%s");
-    hipLaunchKernelGGL(scatter_kernel<false>, dim3((unsigned)B), dim3(256), 0,
+    if ((N + SCATTER_CHUNK - 1) / SCATTER_CHUNK > 65535) return fail(MP_ERR_ARG, "mp_scatter_f32: segments longer than 2^28 samples%s");
+    hipLaunchKernelGGL(scatter_kernel<false>, dim3((unsigned)B, (unsigned)((N + SCATTER_CHUNK - 1) / SCATTER_CHUNK)), dim3(1024), 0,
                        static_cast<hipStream_t>(stream), nullptr, atom, batch, lag, gain, n_events, dict_unit,
                        L, out, N);
     HIP_TRY(hipGetLastError());
@@ -2732,7 +2793,8 @@ int mp_scatter_rows_f32(const float *rows, const int64_t *batch, const int64_t *
     if (n_events == 0 || B == 0) return MP_OK;
     if (!rows || !batch || !lag || !out || L <= 0 || N <= 0 || B < 0 || n_events < 0)
         return fail(MP_ERR_ARG, "mp_scatter_rows_f32: bad arguments%s");
-    hipLaunchKernelGGL(scatter_kernel<true>, dim3((unsigned)B), dim3(256), 0,
+    if ((N + SCATTER_CHUNK - 1) / SCATTER_CHUNK > 65535) return fail(MP_ERR_ARG, "mp_scatter_rows_f32: segments longer than 2^28 samples%s");
+    hipLaunchKernelGGL(scatter_kernel<true>, dim3((unsigned)B, (unsigned)((N + SCATTER_CHUNK - 1) / SCATTER_CHUNK)), dim3(1024), 0,
                        static_cast<hipStream_t>(stream), rows, nullptr, batch, lag, nullptr, n_events, nullptr,
                        L, out, N);
     HIP_TRY(hipGetLastError());
