@@ -2066,7 +2066,8 @@ int fft_iteration(const Geom &g, const Workspace &w, const float *du, int K, int
             // back into the cells, the next round's lower bound rises with them and lists what is left; a round that finds
             // nothing -- or follows a round that listed all its contenders -- leaves at once (two launches, ~8 us a round, against
             // steps of 0.3 .. 1 ms).
-            const int rounds = (f.split && !scan_refine) ? SPLIT_REFINE_ROUNDS : 1;
+            // (two rounds for two halves -- overflows were rare there --, four for four quarters: a round is two launches)
+            const int rounds = !f.split || scan_refine ? 1 : f.split == 1 ? 2 : SPLIT_REFINE_ROUNDS;
             for (int round = 0; round < rounds; ++round) {
             if (scan_refine) {
                 const size_t lds_win = (size_t)(round_up(g.L, 64) + 128) * sizeof(float);
