@@ -347,6 +347,42 @@ def test_scatter_decoder_vs_oracle_and_golden(oracle, golden_dir):
     assert np.array_equal(out.cpu().numpy(), oracle.scatter_rows(rows, batch, lag, 2, 300))
 
 
+@pytest.mark.parametrize("case", ["many_events", "one_segment", "long_rows"])
+def test_scatter_many_events_bitwise(oracle, case):
+    """The decoder is driven by the output (a workgroup owns 4096 samples of a segment and compacts its events 2048 at a
+    time, in list order): several compaction rounds, several chunks per segment, every event in ONE segment, events that
+    overlap many times over, negative lags and lags past the end -- against the oracle's event-by-event loop, bit for bit
+    (per sample the additions happen in list order: modules/matchingpursuit.py:44-56)."""
+    rng = np.random.default_rng({"many_events": 1, "one_segment": 2, "long_rows": 3}[case])
+    A, L, B, N, E = {"many_events": (40, 100, 5, 9000, 6000), "one_segment": (7, 33, 3, 5000, 4500),
+                     "long_rows": (3, 5000, 2, 12000, 300)}[case]
+    du = oracle.unit_norm(rng.standard_normal((A, L)).astype(np.float32))
+    atom = rng.integers(0, A, E)
+    batch = rng.integers(0, B, E) if case != "one_segment" else np.full(E, 1)
+    lag = rng.integers(-L - 5, N + 5, E)
+    gain = rng.standard_normal(E).astype(np.float32)
+    out = torch.zeros(B, N, device=DEV)
+    nat.scatter(torch.from_numpy(atom), torch.from_numpy(batch), torch.from_numpy(lag), torch.from_numpy(gain),
+                torch.from_numpy(du).to(DEV), out)
+    assert np.array_equal(out.cpu().numpy(), oracle.scatter(atom, batch, lag, gain, du, B, N))
+    # ... and onto a signal (scatter_segments(x, events) adds the events to x: modules/matchingpursuit.py:33-34), replayed
+    # here event by event in float32
+    base = rng.standard_normal((B, N)).astype(np.float32)
+    out = torch.from_numpy(base).to(DEV)
+    nat.scatter(torch.from_numpy(atom), torch.from_numpy(batch), torch.from_numpy(lag), torch.from_numpy(gain),
+                torch.from_numpy(du).to(DEV), out)
+    want = base.copy()
+    for e in range(E):
+        lo, hi = max(int(lag[e]), 0), min(int(lag[e]) + L, N)
+        if lo < hi:
+            want[batch[e], lo:hi] = want[batch[e], lo:hi] + du[atom[e], lo - lag[e]:hi - lag[e]] * gain[e]
+    assert np.array_equal(out.cpu().numpy(), want)
+    rows = (du[atom] * gain[:, None]).astype(np.float32)
+    out = torch.zeros(B, N, device=DEV)
+    nat.scatter_rows(torch.from_numpy(rows).to(DEV), torch.from_numpy(batch), torch.from_numpy(lag), out)
+    assert np.array_equal(out.cpu().numpy(), oracle.scatter_rows(rows, batch, lag, B, N))
+
+
 def test_encode_is_deterministic_and_async_safe():
     d, x, K = _inputs("mid")
     du = nat.unit_norm(torch.from_numpy(d).to(DEV))
