@@ -44,8 +44,12 @@ extern "C" {
 #define MP_PATH_FFT 1         /* FFT correlation (modules/conv.py:11-53) as an overlap-save SCREEN,
                                  the few cells that can hold the maximum re-evaluated exactly:
                                  same events as MP_PATH_DIRECT.  A segment whose screen
-                                 overflowed (> 32 inexact contender cells in one step) gets
-                                 out_gain[b, :] = NaN: re-encode it with MP_PATH_INCREMENTAL    */
+                                 overflowed (> 32 inexact contender cells in one step; > 64 / 128
+                                 where the transforms run as two halves / four quarters) gets
+                                 out_gain[b, :] = NaN: re-encode it with MP_PATH_INCREMENTAL.
+                                 Atoms of up to 21782 samples (a 3 L + 190-point transform whole
+                                 in LDS up to 5398, as two 2^14-point halves up to 10859, as four
+                                 quarters beyond); longer atoms: MP_ERR_UNSUPPORTED           */
 #define MP_PATH_INCREMENTAL 2 /* full correlation once, then only the lags an event touched
                                  ([p-L+1, p+L-1]); untouched block maxima are reused        */
 #define MP_PATH_NAIVE 8       /* one-thread-per-lag fmaf chain, no MFMA: validation only    */
