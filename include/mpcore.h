@@ -91,6 +91,8 @@ const char *mp_last_error(void);
  * sampling keeps the timed region honest).  mp_profile_read synchronises, then returns total
  * milliseconds and span counts in ms[3] / count[3] = { full correlate, incremental correlate,
  * everything else (window transform, select, refine, subtract) }, and resets.
+ * Bits 16 .. 18 of `every`: kinds to leave OUT (bit 16 + q = kind q of the list above) -- a timed region that wants its
+ * dominant kernel's durations only records no spans around the selects.
  * Host pointers.  Do not enable while capturing a hipGraph.
  */
 int mp_profile_enable(int every);

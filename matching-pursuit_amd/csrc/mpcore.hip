@@ -58,6 +58,8 @@ struct ProfSpan { hipEvent_t a, b; int kind; };
 std::mutex g_prof_mu;
 struct Profiler {
     std::atomic<int> every{0};   // 0 = off, 1 = every iteration, n = iterations k with k % n == 0
+    std::atomic<int> skip{0};    // bit q: no spans of kind q (an event between two kernels idles the GPU ~8 us: a timed region
+                                 // that only wants its dominant kernel's durations leaves the select spans out)
     std::vector<ProfSpan> spans; // guarded by g_prof_mu
     std::vector<hipEvent_t> pool;
     static bool &armed() { static thread_local bool on = false; return on; }
@@ -71,7 +73,7 @@ struct Profiler {
     }
     void begin(int kind, hipStream_t st) {
         open_end() = nullptr;
-        if (!armed()) return;
+        if (!armed() || ((skip.load(std::memory_order_relaxed) >> kind) & 1)) return;
         std::lock_guard<std::mutex> lk(g_prof_mu);
         ProfSpan s{get(), get(), kind};
         if (!s.a || !s.b) return;
@@ -2362,7 +2364,8 @@ int mp_tune(int key, double value) {
 }
 
 int mp_profile_enable(int on) {
-    g_prof.every.store(on < 0 ? 0 : on);
+    g_prof.every.store(on < 0 ? 0 : (on & 0xffff));
+    g_prof.skip.store(on < 0 ? 0 : ((on >> 16) & 7));
     return MP_OK;
 }
 

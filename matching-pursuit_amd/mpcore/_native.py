@@ -203,9 +203,10 @@ def audit_read():
     return dict(max_ratio=float(r.value), cells=int(n.value), max_quarter_ratio=float(q.value), over_bound=int(o.value))
 
 
-def profile_enable(every=1):
-    """0 / False: off; 1 / True: events around the launches of every iteration; n: every n-th iteration."""
-    _check(lib().mp_profile_enable(int(every)), "mp_profile_enable")
+def profile_enable(every=1, correlate_only=False):
+    """0 / False: off; 1 / True: events around the launches of every iteration; n: every n-th iteration.
+    correlate_only: no spans around the selects (every event between two kernels idles the GPU for ~8 us)."""
+    _check(lib().mp_profile_enable(int(every) | ((4 << 16) if correlate_only and every else 0)), "mp_profile_enable")
 
 
 def profile_read():
