@@ -6,7 +6,9 @@ signatures, event wire formats and on-disk dictionary format (`band_{size}.dat`,
 tensor) as the reference; `samplerate` is accepted and stored but not interpreted (the reference only uses it
 as a default argument, multibanddict.py:63).
 """
+import os
 from collections import Counter, defaultdict
+from concurrent.futures import ThreadPoolExecutor
 from hashlib import sha256
 from typing import Callable, Dict, List, Optional, Tuple
 
@@ -206,13 +208,50 @@ class MultibandDictionaryLearning(object):
             band.load()
 
     # ---- the hot path -----------------------------------------------------------------------------------
+    # The bands are independent encodes of very different sizes, and every one of them is a chain of steps that cannot fill
+    # the GPU by itself at the batch sizes this model runs with (e_2023_3_8: 8 .. 16 segments; the 4096-sample band's
+    # select is one workgroup per SEGMENT).  The reference walks them one after the other (multibanddict.py:318-330);
+    # here each band runs on a stream of its own, driven by a host thread of its own (the per-band calls synchronise with
+    # the host -- the overflow check, the event order -- so one thread cannot keep seven streams fed; the library is
+    # built for concurrent encodes from several threads, tests/test_gpu_parity.py::
+    # test_two_threads_run_the_persistent_form_concurrently).  Same results, band by band: nothing is shared.
+    # MP_BANDS_SEQUENTIAL=1: the reference's loop.
+    _pool = None
+
+    def _map_bands(self, fn, split):
+        sizes = list(self.bands)
+        first = split[sizes[0]]
+        if (len(sizes) < 2 or not torch.is_tensor(first) or first.device.type != "cuda"
+                or os.environ.get("MP_BANDS_SEQUENTIAL") == "1"):
+            return {size: fn(self.bands[size], split[size]) for size in sizes}
+        dev = first.device
+        cur = torch.cuda.current_stream(dev)
+        if getattr(self, "_streams", None) is None or self._streams[0] != dev or len(self._streams[1]) != len(sizes):
+            self._streams = (dev, [torch.cuda.Stream(dev) for _ in sizes])
+        if MultibandDictionaryLearning._pool is None:
+            MultibandDictionaryLearning._pool = ThreadPoolExecutor(max_workers=8, thread_name_prefix="mp-band")
+        grad = torch.is_grad_enabled()
+
+        def run(i):
+            stream = self._streams[1][i]
+            with torch.cuda.device(dev), torch.cuda.stream(stream), torch.set_grad_enabled(grad):
+                stream.wait_stream(cur)        # the band's signal was made on the caller's stream
+                return fn(self.bands[sizes[i]], split[sizes[i]])
+
+        # longest band first: it is the critical path the others hide behind
+        order = sorted(range(len(sizes)), key=lambda i: -sizes[i])
+        futures = {i: MultibandDictionaryLearning._pool.submit(run, i) for i in order}
+        out = {sizes[i]: futures[i].result() for i in range(len(sizes))}
+        for stream in self._streams[1]:
+            cur.wait_stream(stream)            # the caller's stream sees every band's results
+        return out
+
     def learn(self, batch, steps=16):
-        for size, band in fft_frequency_decompose(batch, self.min_size).items():
-            self.bands[size].learn(band, steps)
+        self._map_bands(lambda band, x: band.learn(x, steps), fft_frequency_decompose(batch, self.min_size))
 
     def encode(self, batch, steps, extract_embeddings=None) -> Dict[int, BandEncodingPackage]:
         split = fft_frequency_decompose(batch, self.min_size)
-        return {size: band.encode(split[size], steps, extract_embeddings) for size, band in self.bands.items()}
+        return self._map_bands(lambda band, x: band.encode(x, steps, extract_embeddings), split)
 
     def decode(self, d, shapes=None):
         per_band = {}
@@ -226,9 +265,9 @@ class MultibandDictionaryLearning(object):
 
     def recon(self, batch, steps=16):
         split = fft_frequency_decompose(batch, self.min_size)
-        recon_bands, events = {}, {}
-        for size in self.bands:
-            recon_bands[size], events[size], _ = self.bands[size].recon(split[size], steps)
+        per_band = self._map_bands(lambda band, x: band.recon(x, steps), split)
+        recon_bands = {size: per_band[size][0] for size in self.bands}
+        events = {size: per_band[size][1] for size in self.bands}
         return fft_frequency_recompose(recon_bands, batch.shape[-1]), events
 
     # ---- global <-> per-band event lists (multibanddict.py:404-441) ---------------------------------------

@@ -530,6 +530,40 @@ def test_multiband_encode_decode_matches_reference(golden_dir):
         assert abs(float(torch.norm(band.d, dim=-1).mean()) - 1.0) < 1e-4
 
 
+def test_multiband_bands_run_side_by_side_and_give_the_sequential_results(monkeypatch):
+    """MultibandDictionaryLearning walks its bands on streams of their own, one host thread each (the reference walks them
+    one after the other, multibanddict.py:318-330): same events, same reconstruction, same learned dictionaries as the
+    sequential loop (MP_BANDS_SEQUENTIAL=1), bit for bit -- the bands share nothing."""
+    import modules.multibanddict as mb
+    n, steps = 8192, 6
+    torch.manual_seed(5)
+    x = torch.randn(3, 1, n, device=DEV) * torch.linspace(1.0, 0.1, n, device=DEV)
+
+    def make():
+        torch.manual_seed(7)
+        return mb.MultibandDictionaryLearning(
+            [mb.BandSpec(size, 24, size // 4, device=DEV, signal_samples=n, is_lowest_band=(size == 512))
+             for size in (512, 1024, 2048, 4096, 8192)], n)
+
+    def run(model):
+        enc = model.encode(x, steps)
+        flat = [(e[0], e[1], float(e[2]), float(e[3])) for e in model.flattened_event_tuples(enc)]
+        rec, _ = model.recon(x, steps)
+        model.learn(x, steps)
+        return flat, rec.cpu().numpy(), {s: b.d.cpu().numpy() for s, b in model.bands.items()}
+
+    monkeypatch.setenv("MP_BANDS_SEQUENTIAL", "1")
+    want = run(make())
+    monkeypatch.delenv("MP_BANDS_SEQUENTIAL")
+    model = make()
+    got = run(model)
+    assert model._streams is not None and len(model._streams[1]) == 5     # (the concurrent path ran)
+    assert got[0] == want[0]
+    assert np.array_equal(got[1], want[1])
+    for s in want[2]:
+        assert np.array_equal(got[2][s], want[2][s]), s
+
+
 def test_multiband_on_the_experiment_band_table_matches_reference(golden_dir):
     """MultibandDictionaryLearning on the band table of experiments/archive/e_2023_3_8/experiment.py:351-359 -- seven
     bands of 512 .. 32768 samples, 1024 atoms of band / 4 samples each (atoms of 4096 and 8192 samples: the 2^14- and
