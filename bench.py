@@ -953,7 +953,10 @@ def main():
     # code objects (the library's, and torch's for the handful of tensor operators on the host path -- the coherence
     # cache's device-side comparison alone costs ~45 ms the first time it runs, at the SECOND encode), create the stream
     # pool and build the dictionary's coherence table.  Without this a run with --warmup 1 times that start-up.
-    for _ in range(3):
+    # ... and bring the GPU to the clocks it holds under this load: timed straight after three encodes the K steps read 1 %
+    # (20 steps) to 3 % (5 steps) low against the same schedule measured later in the run (MP_BENCH_INIT_ENCODES=3 shows it).
+    init_encodes = int(os.environ.get("MP_BENCH_INIT_ENCODES", "40"))
+    for _ in range(init_encodes):
         nat.encode(x, du, K_ITERS, path=path, flags=args.flags, want_residual=True)
     torch.cuda.synchronize()
     global WARMUP_STEPS
@@ -980,6 +983,7 @@ def main():
             "path": args.path, "global_batch": world * B_PER_GPU, "n_samples": N, "n_atoms": A,
             "atom_samples": L, "iterations": K_ITERS, "segment_iterations_per_step": world * B_PER_GPU * K_ITERS,
             "parallelism": f"segments sharded over {world} rank(s), no data-path collective",
+            "untimed_initialisation_encodes": init_encodes,
         },
         "roofline": roof,
         "residual_db_mean": round(float(rdb.mean()), 4),
