@@ -68,7 +68,7 @@ PEAK_VALU_GINSTR = N_SIMD * PEAK_CLOCK_HZ / CYCLES_PER_WAVE_INSTR / 1e9   # 614.
 # (spectrum product, transform, running maxima), per kernel: READ FROM THE BUILT CODE OBJECT at run time
 # (scripts/kernel_resources.py::screen_pair_loop disassembles libmpcore.so and counts the loop body); this table is the
 # fallback where the LLVM tools are missing, and tests/test_abi_and_host.py holds it equal to the code object.
-VALU_PER_THREAD_TRANSFORM = {("persistent", 11): 403, ("screen", 11): 404, ("screen", 13): 503}
+VALU_PER_THREAD_TRANSFORM = {("persistent", 11): 403, ("screen", 11): 404, ("screen", 13): 473}
 _valu_cache = {}
 
 

@@ -1975,7 +1975,7 @@ int fft_iteration(const Geom &g, const Workspace &w, const float *du, int K, int
                 if (const int po = screen_pps_override.load(std::memory_order_relaxed); po > 0 && 16 % (C::SLOTS * po) == 0) pps = po;
                 if (quarter || pstep0_big) pps = 4;  // one slot = one quarter of a tile
                 float *subk = (quarter || pstep0_big) ? w.subk : nullptr;
-                const size_t lds_s = ((size_t)C::SLOTS * C::M + C::M / 64 + 64 + (LS == 11 ? SCREEN_TAB_CPX : 0)) * sizeof(cpx);
+                const size_t lds_s = ((size_t)C::SLOTS * C::M + C::M / 64 + 64 + SCREEN_TAB_CPX) * sizeof(cpx);
                 // pair spectra that cannot stay in the L2s: segment-fastest grid order (see the kernel)
                 const bool seg_fast = (size_t)g.NAT * f.NPT * f.M * sizeof(cpx) > (size_t)16 << 20;
                 const unsigned gwp = nw * (16 / (C::SLOTS * pps));
