@@ -133,7 +133,7 @@ struct FormTable {
     // inside the one-launch form
     int persist_two_per_cu_load = 4;           // tasks per CU in flight up to which two workgroups per CU beat three
     int persist_fine_num = 11, persist_fine_den = 2;  // finer tasks while 2 x (their number) <= 11 x CUs (~1400 in flight)
-    int persist_select_workers = 48;           // select workers = min(segments, this)
+    int persist_select_workers = 56;           // select workers = min(segments, this) (scripts/persist_sweep.py: 48 / 56 / 64 at 64 segments 2.768 / 2.742 / 2.756 ms, at 96: 3.919 / 3.816 / 3.845, at 128: 5.034 / 4.994 / 5.067)
     // when the lazy screen is worth its table (host side: _native.lazy_pays)
     int lazy_min_steps = 8, lazy_min_tiles = 4, lazy_always_tiles = 32, lazy_batch_tiles = 384;
 };
