@@ -113,9 +113,13 @@ struct FormTable {
     int64_t fused_min_cells = 65536;      // from here: the whole-cell one-kernel select with block summaries
     int64_t persist_max_cells = 65536;    // the one-launch form keeps its quarter maxima up to here (16 B per cell)
     // one launch (persistent) or launch per step, by load = transform points per step = B x ceil(A / 2) x M
-    double persist_points_table = 96e6;        // with the coherence table: one launch up to here ...
+    double persist_points_table = 140e6;       // with the coherence table: one launch up to here ... (round 4, after the one-launch
+                                               //     form gained most from the round's kernel work -- scripts/form_sweep.py, one launch /
+                                               //     per step at 134 M points: 512 x 512 1283 / 1287, 1024 x 512 766 / 673, 256 x 1024
+                                               //     1528 / 1328, 1024 x 1024 385 / 389; at 268 M: 777 / 778, 385 / 518.  Round 3: 96 M.)
     double persist_points_table_1024 = 100e6;  // ... 1024-point transforms: up to here AND
-    double persist_points_any_batch_1024 = 20e6;  // ... (small loads: one launch at any batch size up to here)
+    double persist_points_any_batch_1024 = 40e6;  // ... (small loads: one launch at any batch size up to here; 512 x 256, 128 segments =
+                                               //     34 M: 1487 / 1418, 256 segments = 67 M: 1477 / 1722.  Round 3: 20 M.)
     int persist_segments_table_1024 = 64;      // ... at most this many segments (form_sweep, one launch / per step, k seg-it/s: 512 x 256
                                                //     64 segments 1296 / 981, 128: 1310 / 1431; 2048 x 256: 64: 456 / 434, 128: 448 / 481;
                                                //     4096 x 256: 16: 177 / 157, 64 = 134 M points: 200 / 238)
@@ -136,6 +140,13 @@ struct FormTable {
     int persist_select_workers = 56;           // select workers = min(segments, this) (scripts/persist_sweep.py: 48 / 56 / 64 at 64 segments 2.768 / 2.742 / 2.756 ms, at 96: 3.919 / 3.816 / 3.845, at 128: 5.034 / 4.994 / 5.067)
     // when the lazy screen is worth its table (host side: _native.lazy_pays)
     int lazy_min_steps = 8, lazy_min_tiles = 4, lazy_always_tiles = 32, lazy_batch_tiles = 384;
+    // the lazy screen's margin (a tile is skipped while its widened upper bounds stay below margin x the best clean lower
+    // bound; any value is exact): inside the persistent launch 0.9 -- 0.7 at 1024-point transforms -- (scripts/
+    // lazy_knob_sweep.py, 0.7 / 0.85 / 0.9 / 0.95, 3 K planted events: 512 x 512, 64 segments 2.742 / 2.605 / 2.574 / 2.554 ms,
+    // 128 segments 5.05 / 4.54 / 4.45 / 4.40, K = 128: 5.79 / 5.62 / 5.56 / 5.49; 2048 x 512: 4.56 / 4.12 / 4.02 / 3.91;
+    // 256 x 256: 1.753 / 1.782 / 1.791 / 1.796; K / 2 planted and unplanted signals: flat up to 0.95, +16 % at 1.0),
+    // between launches 0.85 (mplazy.inc)
+    float lazy_margin_persistent = 0.9f, lazy_margin_persistent_1024 = 0.7f, lazy_margin_steps = 0.85f;
 };
 constexpr FormTable FORM{};
 constexpr int64_t QUARTER_MAX_CELLS = FORM.quarter_max_cells;
@@ -2580,7 +2591,7 @@ static int encode_impl(const float *signal, int64_t B, int64_t N, const float *d
     LazyArgs lz;
     if (path == MP_PATH_FFT && coherence && !conv_model) {
         lz.mu = coherence;
-        lz.margin = lazy_margin_for(true);
+        lz.margin = lazy_margin_for(true, 0);
         lz.reuse = lazy_reuse_for(K, true);
         lz.force = lazy_force.load(std::memory_order_relaxed);
     }
@@ -2980,7 +2991,8 @@ int mp_form_table(double *out, int capacity) {
                         (double)FORM.sub_batches, (double)FORM.persist_two_per_cu_load,
                         (double)FORM.persist_fine_num / FORM.persist_fine_den, (double)FORM.persist_select_workers,
                         (double)FORM.lazy_min_steps, (double)FORM.lazy_min_tiles, (double)FORM.lazy_always_tiles,
-                        (double)FORM.lazy_batch_tiles};
+                        (double)FORM.lazy_batch_tiles, (double)FORM.lazy_margin_persistent, (double)FORM.lazy_margin_persistent_1024,
+                        (double)FORM.lazy_margin_steps};
     const int n = (int)(sizeof(v) / sizeof(v[0]));
     if (out)
         for (int i = 0; i < n && i < capacity; ++i) out[i] = v[i];

@@ -944,15 +944,17 @@ def test_which_form_the_default_schedule_takes():
     assert nat.last_schedule() == streams
     nat.encode(x, du, 7, path=nat.MP_PATH_INCREMENTAL)
     assert nat.last_schedule() == 1
-    # ... and not at every LOAD (csrc/mpcore.hip::encode_impl, scripts/form_sweep.py): 64 segments against a 1024 x 1024
-    # dictionary are 134 M transform points per step and 16.8 MB of pair spectra -- launch per step, on sub-batches; with
-    # the coherence table the fused select and its lazy screen; 16 segments stay in the one-launch form; all identical
+    # ... and not at every LOAD (csrc/mpcore.hip::encode_impl, scripts/form_sweep.py): 96 segments against a 1024 x 1024
+    # dictionary are 201 M transform points per step and 16.8 MB of pair spectra -- launch per step, on sub-batches; with
+    # the coherence table the fused select and its lazy screen (the table's line is at 140 M points since round 4: 64
+    # segments = 134 M take one launch with it, launch per step without); 16 segments stay in the one-launch form; all identical
     d4 = synth.make_dictionary(1024, 1024, seed=55)
     du4 = nat.unit_norm(torch.from_numpy(d4).to(DEV))
-    x4 = torch.from_numpy(synth.make_segments(64, 6000, d4, n_events=12, seed=56)).to(DEV)
+    x4 = torch.from_numpy(synth.make_segments(96, 6000, d4, n_events=12, seed=56)).to(DEV)
     ref4 = nat.encode(x4, du4, 5, path=nat.MP_PATH_FFT, flags=nat.MP_FLAG_NO_OVERLAP, coherence=False)
     mu4 = nat.coherence_table(du4)
-    for n, co, want in ((64, False, streams), (64, mu4, streams), (16, False, -1), (16, mu4, -1), (5, False, -1)):
+    for n, co, want in ((96, False, streams), (96, mu4, streams), (64, False, streams), (64, mu4, -1), (16, False, -1), (16, mu4, -1),
+                        (5, False, -1)):
         nat.lazy_stats()
         out = nat.encode(x4[:n], du4, 5, path=nat.MP_PATH_FFT, coherence=co)
         assert nat.last_schedule() == want, (n, co is not False, nat.last_schedule())
