@@ -137,6 +137,10 @@ struct FormTable {
     // inside the one-launch form
     int persist_two_per_cu_load = 4;           // tasks per CU in flight up to which two workgroups per CU beat three
     int persist_fine_num = 11, persist_fine_den = 2;  // finer tasks while 2 x (their number) <= 11 x CUs (~1400 in flight)
+    int persist_fine_max_logm = 10;            // ... at 1024-point transforms only: at 2048 points they lose from 2 segments up since
+                                               //     round 4 (scripts/fine_sweep.py, 512 x 512, one / two slots per quarter: 4 segments 1.296
+                                               //     / 1.409 ms, 8: 1.387 / 1.477, 16: 1.566 / 1.639, 32: 1.899 / 1.945; 1024 x 512, 16: 2.05
+                                               //     / 2.27; 256 x 256: 1: 1.039 / 0.993, 8: 1.116 / 1.103, 64: 2.040 / 1.770)
     int persist_select_workers = 56;           // select workers = min(segments, this) (scripts/persist_sweep.py: 48 / 56 / 64 at 64 segments 2.768 / 2.742 / 2.756 ms, at 96: 3.919 / 3.816 / 3.845, at 128: 5.034 / 4.994 / 5.067)
     // when the lazy screen is worth its table (host side: _native.lazy_pays)
     int lazy_min_steps = 8, lazy_min_tiles = 4, lazy_always_tiles = 32, lazy_batch_tiles = 384;
@@ -2992,7 +2996,7 @@ int mp_form_table(double *out, int capacity) {
                         (double)FORM.persist_fine_num / FORM.persist_fine_den, (double)FORM.persist_select_workers,
                         (double)FORM.lazy_min_steps, (double)FORM.lazy_min_tiles, (double)FORM.lazy_always_tiles,
                         (double)FORM.lazy_batch_tiles, (double)FORM.lazy_margin_persistent, (double)FORM.lazy_margin_persistent_1024,
-                        (double)FORM.lazy_margin_steps};
+                        (double)FORM.lazy_margin_steps, (double)FORM.persist_fine_max_logm};
     const int n = (int)(sizeof(v) / sizeof(v[0]));
     if (out)
         for (int i = 0; i < n && i < capacity; ++i) out[i] = v[i];

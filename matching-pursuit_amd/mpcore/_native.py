@@ -421,7 +421,8 @@ FORM_FIELDS = ("quarter_max_cells", "fused_min_cells", "persist_max_cells", "per
                "persist_points_any_batch_1024", "persist_segments_table_1024", "sub_batch_min_segments", "persist_spectra_bytes", "persist_points_fit", "persist_points_nofit", "short_ratio",
                "short_logm_always", "short_logm_small", "short_small_segments", "sub_batches", "persist_two_per_cu_load",
                "persist_fine_tasks_per_cu", "persist_select_workers", "lazy_min_steps", "lazy_min_tiles", "lazy_always_tiles",
-               "lazy_batch_tiles", "lazy_margin_persistent", "lazy_margin_persistent_1024", "lazy_margin_steps")
+               "lazy_batch_tiles", "lazy_margin_persistent", "lazy_margin_persistent_1024", "lazy_margin_steps",
+               "persist_fine_max_logm")
 _form = None
 
 
