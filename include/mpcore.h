@@ -120,7 +120,7 @@ int mp_profile_enable(int every);
                                      up to 96 steps and 1 beyond, between launches (the launch-per-step form) 4               */
 #define MP_TUNE_LAZY_MARGIN 10    /* lazy screen (mp_encode_lazy_f32): a tile is skipped when its dirty cells' widened upper
                                      bounds stay below margin x the best lower bound of the untouched blocks (0 < margin <= 1;
-                                     0 = the defaults: 0.9 inside the persistent launch (0.7 at 1024-point transforms), 0.85 between launches; any value is
+                                     0 = the defaults: 0.9 inside the persistent launch (0.7 at 1024-point transforms), 0.95 between launches; any value is
                                      exact, smaller = fewer skips and fewer stale contenders)                                */
 #define MP_TUNE_LAZY_RADIUS 13    /* lazy screen: the run's floor is the (K + K/16 + 1)-th largest PEAK among the blocks' lower bounds after step
                                      0 -- a block counts if it is the best within this many blocks either side; 0 (default) =

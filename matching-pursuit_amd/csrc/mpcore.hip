@@ -149,8 +149,11 @@ struct FormTable {
     // lazy_knob_sweep.py, 0.7 / 0.85 / 0.9 / 0.95, 3 K planted events: 512 x 512, 64 segments 2.742 / 2.605 / 2.574 / 2.554 ms,
     // 128 segments 5.05 / 4.54 / 4.45 / 4.40, K = 128: 5.79 / 5.62 / 5.56 / 5.49; 2048 x 512: 4.56 / 4.12 / 4.02 / 3.91;
     // 256 x 256: 1.753 / 1.782 / 1.791 / 1.796; K / 2 planted and unplanted signals: flat up to 0.95, +16 % at 1.0),
-    // between launches 0.85 (mplazy.inc)
-    float lazy_margin_persistent = 0.9f, lazy_margin_persistent_1024 = 0.7f, lazy_margin_steps = 0.85f;
+    // between launches 0.95 (round 3: 0.85; scripts/c3_margin.py, 0.85 / 0.9 / 0.95 / 1.0: BASELINE configs[3] 344 / 327 / 313 / 301 ms
+    // = 95.4 / 100.2 / 104.7 / 108.9 k, without planted events 249 / - / 246 / 253 at 32 segments; 1024 x 1024, 128 segments: 16.3 /
+    // 14.8 / 14.0 / 13.6 ms, with K / 2 planted events 25.6 / 24.4 / 24.3 / 24.2; 512 x 512, 256 segments, K / 2 planted: 14.9 / 13.8 /
+    // 12.9 / 13.0)
+    float lazy_margin_persistent = 0.9f, lazy_margin_persistent_1024 = 0.7f, lazy_margin_steps = 0.95f;
 };
 constexpr FormTable FORM{};
 constexpr int64_t QUARTER_MAX_CELLS = FORM.quarter_max_cells;
