@@ -114,7 +114,7 @@ int mp_profile_enable(int every);
                                     (0 = heuristic: one per ~512 workers)                                          */
 #define MP_TUNE_PERSIST_WORKERS 7 /* persistent form: workgroups of the launch (0 = heuristic: 2 or 3 per CU by the
                                      number of screen tasks the batch can have in flight)                          */
-#define MP_TUNE_PERSIST_SELECTS 8 /* persistent form: how many of them are select workers (0 = min(segments, 56))    */
+#define MP_TUNE_PERSIST_SELECTS 8 /* persistent form: how many of them are select workers (0 = min(segments, 64))    */
 #define MP_TUNE_LAZY_REUSE 12     /* lazy screen: how often a cell's bound may be widened before the cell is screened again the next
                                      time it is dirty: 1 .. 4 (4 = no cap); 0 (default) = by form: inside the persistent launch 4
                                      up to 96 steps and 1 beyond, between launches (the launch-per-step form) 4               */

@@ -141,7 +141,7 @@ struct FormTable {
                                                //     round 4 (scripts/fine_sweep.py, 512 x 512, one / two slots per quarter: 4 segments 1.296
                                                //     / 1.409 ms, 8: 1.387 / 1.477, 16: 1.566 / 1.639, 32: 1.899 / 1.945; 1024 x 512, 16: 2.05
                                                //     / 2.27; 256 x 256: 1: 1.039 / 0.993, 8: 1.116 / 1.103, 64: 2.040 / 1.770)
-    int persist_select_workers = 56;           // select workers = min(segments, this) (scripts/persist_sweep.py: 48 / 56 / 64 at 64 segments 2.768 / 2.742 / 2.756 ms, at 96: 3.919 / 3.816 / 3.845, at 128: 5.034 / 4.994 / 5.067)
+    int persist_select_workers = 64;           // select workers = min(segments, this) (scripts/persist_sweep.py at the lazy margin 0.9: 48 / 56 / 64 / 80 at 64 segments 2.766 / 2.626 / 2.608 / 2.604 ms, at 128: 4.803 / 4.505 / 4.443 / 4.447; round 3: 48)
     // when the lazy screen is worth its table (host side: _native.lazy_pays)
     int lazy_min_steps = 8, lazy_min_tiles = 4, lazy_always_tiles = 32, lazy_batch_tiles = 384;
     // the lazy screen's margin (a tile is skipped while its widened upper bounds stay below margin x the best clean lower
