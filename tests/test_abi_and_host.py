@@ -270,6 +270,28 @@ def test_bench_prices_the_screen_with_the_instruction_counts_of_the_built_code()
     assert f["frac"] < f["frac_issue"] and abs(f["frac"] / f["frac_issue"] - 324 / 403) < 5e-3 and f["frac_flops"] < f["frac"]
 
 
+def test_event_grouping_matches_the_composite_key_sort():
+    """group_events_by_atom (the layout of flatten_atom_dict, modules/matchingpursuit.py:61-65: groups in first-selection
+    order, each in (step, batch) order) sorts 16-bit group numbers over the step-major layout; the statement it replaces --
+    a stable sort of the composite key (group, step, batch) -- must give the same permutation and counts, ragged sizes
+    and atoms of another rank (absent from `order`) included."""
+    from mpcore import matchingpursuit as mpm
+    rng = np.random.default_rng(3)
+    for B, K, A in ((64, 64, 512), (3, 5, 7), (1, 1, 1), (7, 0, 4), (5, 9, 70000)):
+        a = rng.integers(0, A, (B, K))
+        order = mpm.first_selection_order(a) if K else []
+        if B == 3:
+            order = order[:-1]                      # one atom selected here belongs to another rank's list
+        perm, counts = mpm.group_events_by_atom(a, order, A)
+        rank_of = np.full(A, len(order), dtype=np.int64)
+        if len(order):
+            rank_of[np.asarray(order, dtype=np.int64)] = np.arange(len(order))
+        r = rank_of[a]
+        key = (r * K + np.arange(K)[None, :]) * max(B, 1) + np.arange(B)[:, None]
+        assert np.array_equal(perm.numpy(), np.argsort(key.reshape(-1), kind="stable")), (B, K, A)
+        assert counts == np.bincount(r.reshape(-1), minlength=len(order) + 1)[: len(order)].tolist()
+
+
 def test_dictionary_levels_host_helper_matches_brute_force():
     """mp_dictionary_levels_host (host arrays only, no GPU): level[g] = 0 if group g shares no sample with an earlier
     group, else 1 + the highest level among the earlier groups it overlaps; overlap[g] flags two events of the same
